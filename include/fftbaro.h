@@ -1,0 +1,143 @@
+/*
+ * fftbaro.h -- C ABI of the MI355X-native pseudospectral barotropic-vorticity engine.
+ *
+ * Drop-in boundary for the hot path of meteorologytoday/XLab-FFTBarotropic: every entry
+ * point below names the reference interface it replaces (paths relative to the reference
+ * root).  Plain pointers and sizes only; no C++/torch types.  All `float *` arguments named
+ * d_* are DEVICE pointers (HIP); spectra are interleaved (re,im) float32 in the reference's
+ * half-spectrum layout HIDX(i,j) = (ny/2+1)*i + j (configuration.hpp:32), real fields are
+ * IDX(i,j) = ny*i + j (configuration.hpp:31).
+ *
+ * Every function returns an int status (FB_OK == 0); the reference's methods are `void` with
+ * no error path (fftwfop.hpp:20-24) -- see INTEGRATION.md for the binding a maintainer adds.
+ * Work is enqueued on the context's HIP stream (default: the null stream); functions do not
+ * synchronise unless stated.
+ *
+ * There is NO CPU fallback: when no HIP device is usable fb_create fails with FB_EHIP.
+ */
+#ifndef FFTBARO_H
+#define FFTBARO_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FB_OK            0
+#define FB_EINVAL        1   /* bad argument (null pointer, unsupported size, ...) */
+#define FB_ENOMEM        2   /* host or device allocation failed                  */
+#define FB_EHIP          3   /* HIP runtime error; see fb_last_error()            */
+#define FB_EIO           4   /* file open / short read / short write              */
+#define FB_EUNSUPPORTED  5   /* grid size not supported by the kernels            */
+
+const char *fb_strerror(int status);
+const char *fb_last_error(void);          /* thread-local detail of the last failure */
+int fb_version(void);                      /* 100*major + minor                       */
+/* 1 if (nx,ny) is supported: powers of two, 64 <= n <= 16384 */
+int fb_size_supported(int nx, int ny);
+
+/* ---------------------------------------------------------------------------------------
+ * Context = operator tables + FFT plans.
+ * Replaces: fftwf_operation<XPTS,YPTS>::fftwf_operation(Lx,Ly) / ~fftwf_operation()
+ *           (fftwfop.hpp:18-19, fftwfop.cpp:5-85) and the eight fftwf_plan_dft_{r2c,c2r}_2d
+ *           calls of main.cpp:126-135.  Grid size is a run-time argument here
+ *           (configuration.hpp:18-21 fixes it at compile time).
+ * ------------------------------------------------------------------------------------- */
+typedef struct fb_ctx fb_ctx;
+int fb_create(fb_ctx **out, int nx, int ny, float lx, float ly);
+int fb_destroy(fb_ctx *ctx);
+int fb_set_stream(fb_ctx *ctx, void *hip_stream);     /* hipStream_t; NULL = null stream */
+int fb_synchronize(fb_ctx *ctx);                       /* hipStreamSynchronize            */
+/* copies the five coefficient tables to HOST buffers (any may be NULL): gradx_coe[nx],
+ * grady_coe[ny/2+1], laplacian_coe / laplacian_coe_inverse / dealiasing_mask [nx*(ny/2+1)]
+ * (fftwfop.cpp:15-68; the debug print of :26-36,70-77) */
+int fb_get_tables(fb_ctx *ctx, float *gradx_coe, float *grady_coe, float *laplacian_coe,
+                  float *laplacian_coe_inverse, float *dealiasing_mask);
+
+/* ---------------------------------------------------------------------------------------
+ * Buffers.  Replaces fftwf_malloc / fftwf_free (main.cpp:103-123) with device memory.
+ * ------------------------------------------------------------------------------------- */
+int fb_malloc(void **d_ptr, size_t bytes);
+int fb_free(void *d_ptr);
+int fb_memcpy_h2d(fb_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);  /* synchronous */
+int fb_memcpy_d2h(fb_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);  /* synchronous */
+int fb_memset0(fb_ctx *ctx, void *d_dst, size_t bytes);
+
+/* ---------------------------------------------------------------------------------------
+ * Spectral operators on device half spectra (nx*(ny/2+1) complex).  in == out is allowed
+ * (main-shallow-water.cpp:327, invert_pres.cpp:148-150).
+ * Replaces fftwf_operation::gradx/grady/laplacian/invertLaplacian/dealiase
+ * (fftwfop.hpp:20-24, fftwfop.cpp:87-124).  Bit-exact with the reference's float32 forms.
+ * ------------------------------------------------------------------------------------- */
+int fb_gradx(fb_ctx *ctx, const float *d_in, float *d_out);
+int fb_grady(fb_ctx *ctx, const float *d_in, float *d_out);
+int fb_laplacian(fb_ctx *ctx, const float *d_in, float *d_out);
+int fb_invert_laplacian(fb_ctx *ctx, const float *d_in, float *d_out);
+int fb_dealiase(fb_ctx *ctx, const float *d_in, float *d_out);
+
+/* ---------------------------------------------------------------------------------------
+ * 2-D FFTs.  Replaces fftwf_execute() on the r2c / c2r plans (main.cpp:154,168,186,200,214,
+ * 237,256,275).  Unnormalised, r2c sign -, c2r sign +; c2r accepts non-Hermitian input with
+ * FFTW's semantics (SURVEY.md note N2) and -- unlike FFTW -- preserves its input, so the
+ * copy_for_c2r dance of main.cpp:273,281 is unnecessary (harmless if kept).
+ * fb_c2r with normalize != 0 also applies fftwf_backward_normalize (main.cpp:37-41).
+ * ------------------------------------------------------------------------------------- */
+int fb_r2c(fb_ctx *ctx, const float *d_in_real, float *d_out_spec);
+int fb_c2r(fb_ctx *ctx, const float *d_in_spec, float *d_out_real, int normalize);
+
+/* ---------------------------------------------------------------------------------------
+ * Pointwise sweeps the reference driver does in its lambdas.
+ * ------------------------------------------------------------------------------------- */
+/* data[i] /= GRIDS                                   fftwf_backward_normalize, main.cpp:37-41 */
+int fb_backward_normalize(fb_ctx *ctx, float *d_real);
+/* data[i] = -data[i]                                 main.cpp:201                            */
+int fb_negate(fb_ctx *ctx, float *d_real);
+/* out = -u*dzdx - v*dzdy + src (src NULL = 0)        main.cpp:225-227                        */
+int fb_jacobian(fb_ctx *ctx, const float *d_u, const float *d_v, const float *d_dzdx,
+                const float *d_dzdy, const float *d_src, float *d_out);
+/* acc += x * a   on spectra                          main.cpp:240-243 (viscous add)          */
+int fb_spec_axpy(fb_ctx *ctx, float *d_acc, const float *d_x, float a);
+/* out = base + rk * a  on spectra                    evolve(), main.cpp:246-251              */
+int fb_spec_evolve(fb_ctx *ctx, const float *d_base, const float *d_rk, float a, float *d_out);
+/* out = base + (k1 + 2 k2 + 2 k3 + k4) * dt / 6      main.cpp:309-312                        */
+int fb_spec_rk4_combine(fb_ctx *ctx, const float *d_base, const float *d_k1, const float *d_k2,
+                        const float *d_k3, const float *d_k4, float dt, float *d_out);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused RK4 model: the hot loop of main.cpp:259-323 / main-shallow-water.cpp:277-338 with
+ * the state resident in HBM.  One fb_model_step() == one iteration of the reference's step
+ * loop body without the record path (a13-a15 of SURVEY.md section 8 fused into the FFT passes).
+ * ------------------------------------------------------------------------------------- */
+typedef struct fb_model fb_model;
+int fb_model_create(fb_model **out, fb_ctx *ctx, float nu, float dt);      /* NU, dt: configuration.hpp:17,34 */
+int fb_model_destroy(fb_model *m);
+/* readField + fftwf_execute(p_fwd_vort)              main.cpp:143-144,256 */
+int fb_model_set_vort(fb_model *m, const float *d_vort_real);
+/* vort_src (device real field, copied; NULL = zeros) main.cpp:110,226; refreshed per step by
+ * VortSrcRecipeReader::read in main-shallow-water.cpp:304 */
+int fb_model_set_source(fb_model *m, const float *d_src_real);
+int fb_model_step(fb_model *m, int nsteps);
+/* record path: c2r of a copy of vort_c + normalise   main.cpp:273-281 */
+int fb_model_get_vort(fb_model *m, float *d_vort_real);
+/* stage-0 record dumps psi, u, v (any may be NULL)   main.cpp:181-222 */
+int fb_model_get_diag(fb_model *m, float *d_psi, float *d_u, float *d_v);
+/* vort_c in the reference layout */
+int fb_model_get_spectrum(fb_model *m, float *d_spec);
+int fb_model_set_spectrum(fb_model *m, const float *d_spec);
+/* bytes of HBM the model holds, and the algorithmic bytes of one step (320*nx*ny) */
+int fb_model_info(fb_model *m, size_t *hbm_bytes, size_t *alg_bytes_per_step);
+/* times `nsteps` steps with HIP events on the model's stream; returns ms total and, if
+ * kernel_ms != NULL, the summed duration of the dominant kernel class (column-mid) */
+int fb_model_time_steps(fb_model *m, int nsteps, float *total_ms);
+
+/* ---------------------------------------------------------------------------------------
+ * Field I/O on HOST buffers.  Replaces writeField / readField (fieldio.hpp:5-6,
+ * fieldio.cpp:7-33): identical bytes on disk and identical stderr lines, plus a status.
+ * ------------------------------------------------------------------------------------- */
+int fb_write_field(const char *filename, const float *h_data, size_t len);
+int fb_read_field(const char *filename, float *h_data, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFTBARO_H */

@@ -1,0 +1,249 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the fixtures.
+
+Tolerances (float32 arithmetic, stated per north_star): operators / pointwise sweeps are
+bit-exact; a single 2-D FFT agrees to 5e-7 relative L2 (observed oracle-vs-fp64: 1.5e-7);
+the vorticity field after N RK4 steps agrees to 1e-5 relative L2.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+L = 600000.0
+
+
+@pytest.fixture(scope="module")
+def X():
+    import xlab_fftbarotropic_amd as X
+    return X
+
+
+@pytest.fixture(scope="module")
+def O():
+    import oracle_py as O
+    return O
+
+
+@pytest.fixture(scope="module")
+def R():
+    import ref_numpy as R
+    return R
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    return torch
+
+
+def _rand_spec(nx, ny, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((nx, ny // 2 + 1)) + 1j * rng.standard_normal((nx, ny // 2 + 1))).astype(np.complex64)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("nx,ny", [(64, 64), (256, 256), (128, 64), (64, 256)])
+def test_tables_bit_exact(X, O, nx, ny):
+    fop = X.FftwfOperation(nx, ny, L, L)
+    got = fop.tables()
+    want = O.Operators(nx, ny, L, L).tables()
+    for g, w in zip(got, want):
+        assert np.array_equal(_bits(g), _bits(w))
+
+
+@pytest.mark.parametrize("nx,ny", [(64, 64), (256, 256), (128, 64), (1024, 1024)])
+def test_operators_bit_exact(X, O, torch, nx, ny):
+    fop = X.FftwfOperation(nx, ny, L, L)
+    ops = O.Operators(nx, ny, L, L)
+    s = _rand_spec(nx, ny, 11)
+    d = torch.from_numpy(s).cuda()
+    for name in ("gradx", "grady", "laplacian", "invertLaplacian", "dealiase"):
+        got = getattr(fop, name)(d).cpu().numpy()
+        want = getattr(ops, name)(s)
+        assert np.array_equal(_bits(got), _bits(want)), name
+    # in == out
+    e = d.clone()
+    fop.dealiase(e, out=e)
+    assert np.array_equal(_bits(e.cpu().numpy()), _bits(ops.dealiase(s)))
+    e = d.clone()
+    fop.gradx(e, out=e)
+    assert np.array_equal(_bits(e.cpu().numpy()), _bits(ops.gradx(s)))
+
+
+def test_pointwise_sweeps_bit_exact(X, torch):
+    nx = ny = 128
+    fop = X.FftwfOperation(nx, ny, L, L)
+    rng = np.random.default_rng(5)
+    f = [rng.standard_normal((nx, ny)).astype(np.float32) for _ in range(5)]
+    d = [torch.from_numpy(a).cuda() for a in f]
+    got = fop.jacobian(d[0], d[1], d[2], d[3], d[4]).cpu().numpy()
+    want = -f[0] * f[2] - f[1] * f[3] + f[4]                                # main.cpp:225-227
+    assert np.array_equal(_bits(got), _bits(want))
+    got = fop.jacobian(d[0], d[1], d[2], d[3], None).cpu().numpy()
+    assert np.array_equal(_bits(got), _bits(-f[0] * f[2] - f[1] * f[3] + np.float32(0)))
+    a = d[0].clone()
+    fop.backward_normalize(a)
+    assert np.array_equal(_bits(a.cpu().numpy()), _bits(f[0] / np.float32(nx * ny)))
+    a = d[0].clone()
+    fop.negate(a)
+    assert np.array_equal(_bits(a.cpu().numpy()), _bits(-f[0]))
+    s = [_rand_spec(nx, ny, 20 + i) for i in range(5)]
+    ds = [torch.from_numpy(a).cuda() for a in s]
+    nu, dt = np.float32(6.5), np.float32(3.0)
+    acc = ds[0].clone()
+    fop.spec_axpy(acc, ds[1], float(nu))
+    assert np.array_equal(_bits(acc.cpu().numpy()), _bits(s[0] + s[1] * nu))
+    ev = fop.spec_evolve(ds[0], ds[1], float(dt / np.float32(2)))
+    assert np.array_equal(_bits(ev.cpu().numpy()), _bits(s[0] + s[1] * (dt / np.float32(2))))
+    sv = [a.view(np.float32) for a in s]
+    want = sv[0] + (sv[1] + np.float32(2) * sv[2] + np.float32(2) * sv[3] + sv[4]) * dt / np.float32(6)
+    got = fop.spec_rk4_combine(ds[0], ds[1], ds[2], ds[3], ds[4], float(dt)).cpu().numpy().view(np.float32)
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+@pytest.mark.parametrize("nx,ny", [(64, 64), (128, 64), (64, 128), (256, 256), (512, 512), (1024, 1024),
+                                   (2048, 2048), (4096, 4096)])
+def test_r2c_c2r_vs_oracle(X, O, R, torch, nx, ny):
+    fop = X.FftwfOperation(nx, ny, L, L)
+    rng = np.random.default_rng(nx * 3 + ny)
+    f = rng.standard_normal((nx, ny)).astype(np.float32)
+    spec = fop.r2c(torch.from_numpy(f).cuda())
+    assert R.rel_l2(spec.cpu().numpy().view(np.float32), O.r2c(f).view(np.float32)) < 5e-7
+    back = fop.c2r(spec, normalize=True).cpu().numpy()
+    assert R.rel_l2(back, f) < 6e-7                               # FFT round trip
+    s = _rand_spec(nx, ny, 3)                                     # non-Hermitian input, SURVEY note N2
+    ds = torch.from_numpy(s).cuda()
+    got = fop.c2r(ds).cpu().numpy()
+    assert R.rel_l2(got, O.c2r(s, ny)) < 5e-7
+    assert np.array_equal(_bits(ds.cpu().numpy()), _bits(s))      # input preserved
+
+
+def test_r2c_vs_numpy_fp64_large(X, R, torch):
+    """8192^2 (config 4 grid): checked against numpy fp64 directly."""
+    n = 8192
+    fop = X.FftwfOperation(n, n, L, L)
+    rng = np.random.default_rng(1)
+    f = rng.standard_normal((n, n)).astype(np.float32)
+    spec = fop.r2c(torch.from_numpy(f).cuda()).cpu().numpy()
+    want = np.fft.rfft2(f.astype(np.float64))
+    assert R.rel_l2(spec.view(np.float32), want.view(np.float64)) < 5e-7
+
+
+def test_model_golden_64(X, R):
+    G = np.load(os.path.join(HERE, "golden", "golden.npz"))
+    m = X.Model(64, 64)
+    m.set_vort(G["fp64_vort0"])
+    psi, u, v = [a.cpu().numpy() for a in m.diag()]
+    assert R.rel_l2(psi, G["fp64_psi0"]) < 1e-6
+    assert R.rel_l2(u, G["fp64_u0"]) < 1e-6
+    assert R.rel_l2(v, G["fp64_v0"]) < 1e-6
+    done = 0
+    for upto in (1, 10, 100):
+        m.step(upto - done)
+        done = upto
+        assert R.rel_l2(m.vort().cpu().numpy(), G["fp64_vort_step%d" % upto]) < 1e-5, upto
+
+
+@pytest.mark.parametrize("n,kind,steps", [(256, "elliptic", 100), (128, "gaussian", 50), (512, "kuo2004", 20)])
+def test_model_vs_oracle(X, O, R, n, kind, steps):
+    v0 = O.make_field(kind, n)
+    m = X.Model(n, n)
+    m.set_vort(v0)
+    mo = O.Model(n, n)
+    mo.set_vort(v0)
+    assert R.rel_l2(m.spectrum().cpu().numpy().view(np.float32), mo.spectrum().view(np.float32)) < 5e-7
+    m.step(steps)
+    mo.step(steps)
+    assert R.rel_l2(m.vort().cpu().numpy(), mo.vort()) < 1e-5
+    s_gpu, s_cpu = m.spectrum().cpu().numpy(), mo.spectrum()
+    assert R.rel_l2(s_gpu.view(np.float32), s_cpu.view(np.float32)) < 1e-5
+    # split calls continue the pipeline identically
+    m2 = X.Model(n, n)
+    m2.set_vort(v0)
+    for _ in range(steps):
+        m2.step(1)
+    assert np.array_equal(_bits(m2.vort().cpu().numpy()), _bits(m.vort().cpu().numpy()))
+
+
+def test_model_nonsquare(X, O, R):
+    nx, ny = 128, 256
+    rng = np.random.default_rng(3)
+    v0 = (1e-3 * rng.standard_normal((nx, ny))).astype(np.float32)
+    v0 = O.c2r(O.Operators(nx, ny, L, L).dealiase(O.r2c(v0)), ny) / np.float32(nx * ny)
+    m = X.Model(nx, ny)
+    m.set_vort(v0)
+    mo = O.Model(nx, ny)
+    mo.set_vort(v0)
+    m.step(10)
+    mo.step(10)
+    assert R.rel_l2(m.vort().cpu().numpy(), mo.vort()) < 1e-5
+
+
+def test_model_source_and_invariants(X, O, R):
+    n = 128
+    src = np.zeros((n, n), dtype=np.float32)
+    O.add_cake(src, L, L, L / 2 + 50000.0, L / 2, 3e-3 / 10800.0, 30000.0)       # vort_src_input.cpp:46
+    v0 = O.make_field("kuo2004", n)
+    m = X.Model(n, n)
+    m.set_vort(v0)
+    m.set_source(src)
+    mo = O.Model(n, n)
+    mo.set_vort(v0)
+    mo.set_source(src)
+    m.step(20)
+    mo.step(20)
+    assert R.rel_l2(m.vort().cpu().numpy(), mo.vort()) < 1e-5
+    # without source: (0,0) mode conserved exactly, frozen modes outside the mask (SURVEY note N1)
+    m.set_source(None)
+    s0 = m.spectrum().cpu().numpy()
+    m.step(5)
+    s1 = m.spectrum().cpu().numpy()
+    assert s1[0, 0] == s0[0, 0]
+    mask = O.Operators(n, n, L, L).tables()[4]
+    assert np.array_equal(_bits(s1[mask == 0]), _bits(s0[mask == 0]))
+
+
+def test_set_get_spectrum_roundtrip(X, torch):
+    n = 256
+    m = X.Model(n, n)
+    s = torch.from_numpy(_rand_spec(n, n, 8)).cuda()
+    m.set_spectrum(s)
+    assert torch.equal(m.spectrum(), s)
+
+
+def test_full_size_properties_4096(X, O, R, torch):
+    """BASELINE config 3 grid (4096^2 Kuo2004): size-independent properties + short oracle run."""
+    n = 4096
+    dt = 3.0 * 1024 / n
+    v0 = O.make_field("kuo2004", n)
+    m = X.Model(n, n, dt=dt)
+    m.set_vort(v0)
+    assert R.rel_l2(m.vort().cpu().numpy(), v0) < 1e-6            # c2r(r2c(x))/GRIDS = x
+    s0 = m.spectrum().cpu().numpy()
+    m.step(2)
+    s1 = m.spectrum().cpu().numpy()
+    assert s1[0, 0] == s0[0, 0]                                   # mean vorticity conserved exactly
+    mo = O.Model(n, n, dt=dt)
+    mo.set_vort(v0)
+    mo.step(2)
+    assert R.rel_l2(m.vort().cpu().numpy(), mo.vort()) < 1e-5
+    e0 = float((v0.astype(np.float64) ** 2).sum())
+    e1 = float((m.vort().cpu().numpy().astype(np.float64) ** 2).sum())
+    assert e1 <= e0 * (1 + 1e-6)                                  # enstrophy does not grow
+
+
+def test_errors(X):
+    import ctypes as C
+    Lb = X.lib()
+    h = C.c_void_p()
+    assert Lb.fb_create(C.byref(h), 768, 768, L, L) == 5          # FB_EUNSUPPORTED (non power of two)
+    assert Lb.fb_create(C.byref(h), 256, 256, -1.0, L) == 1       # FB_EINVAL
+    assert Lb.fb_gradx(None, None, None) == 1
+    with pytest.raises(X.FftBaroError):
+        X.read_field("/nonexistent/file.bin", 4)

@@ -1,0 +1,290 @@
+// fb_fft_core.h -- device-side FFT building blocks for gfx950 (wave64, LDS-staged radix butterflies).
+//
+// No reference counterpart: the reference takes its FFTs from FFTW3f (main.cpp:126-135).
+// Conventions are FFTW's: DIR = -1 forward (exp(-2 pi i jk/n)), DIR = +1 backward, unnormalised.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float2 cf;
+
+#define FB_DEV __device__ __forceinline__
+
+FB_DEV cf cf_make(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+FB_DEV cf cadd(cf a, cf b) { return cf_make(a.x + b.x, a.y + b.y); }
+FB_DEV cf csub(cf a, cf b) { return cf_make(a.x - b.x, a.y - b.y); }
+FB_DEV cf cmul(cf a, cf b) { return cf_make(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+FB_DEV cf cmulc(cf a, cf b) { return cf_make(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
+// multiply by the direction's table twiddle: forward uses w, backward conj(w)
+template <int DIR> FB_DEV cf cmul_dir(cf a, cf w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
+// multiply by -i (forward) or +i (backward)
+template <int DIR> FB_DEV cf mul_mi(cf a) { return DIR < 0 ? cf_make(a.y, -a.x) : cf_make(-a.y, a.x); }
+
+#define FB_SQRT1_2 0.70710678118654752440f
+#define FB_C16_1 0.92387953251128675613f   /* cos(pi/8) */
+#define FB_S16_1 0.38268343236508977173f   /* sin(pi/8) */
+
+// multiply by W_16^M (forward) or its conjugate (backward), M in 0..15 compile-time
+template <int M, int DIR> FB_DEV cf mul_w16(cf a)
+{
+    constexpr int m = M & 15;
+    if constexpr (m == 0) return a;
+    else if constexpr (m == 4) return mul_mi<DIR>(a);
+    else if constexpr (m == 8) return cf_make(-a.x, -a.y);
+    else if constexpr (m == 12) return mul_mi<-DIR>(a);
+    else {
+        // W^m = (c, -s) forward with c = cos(2 pi m/16), s = sin(2 pi m/16)
+        constexpr float c = (m == 1 || m == 15) ? FB_C16_1 : (m == 2 || m == 14) ? FB_SQRT1_2 :
+                            (m == 3 || m == 13) ? FB_S16_1 : (m == 5 || m == 11) ? -FB_S16_1 :
+                            (m == 6 || m == 10) ? -FB_SQRT1_2 : /* 7, 9 */ -FB_C16_1;
+        constexpr float s = (m == 1 || m == 7) ? FB_S16_1 : (m == 2 || m == 6) ? FB_SQRT1_2 :
+                            (m == 3 || m == 5) ? FB_C16_1 : (m == 9 || m == 15) ? -FB_S16_1 :
+                            (m == 10 || m == 14) ? -FB_SQRT1_2 : /* 11, 13 */ -FB_C16_1;
+        constexpr float si = DIR < 0 ? -s : s;       // imaginary part of the twiddle
+        return cf_make(a.x * c - a.y * si, a.x * si + a.y * c);
+    }
+}
+
+// ---- in-register radix butterflies, natural-order output -----------------------------------
+template <int DIR> FB_DEV void fft2(cf &a, cf &b) { cf t = a; a = cadd(t, b); b = csub(t, b); }
+
+template <int DIR> FB_DEV void fft4(cf &a0, cf &a1, cf &a2, cf &a3)
+{
+    cf s0 = cadd(a0, a2), s1 = csub(a0, a2), s2 = cadd(a1, a3), s3 = mul_mi<DIR>(csub(a1, a3));
+    a0 = cadd(s0, s2); a1 = cadd(s1, s3); a2 = csub(s0, s2); a3 = csub(s1, s3);
+}
+
+template <int R, int DIR> struct Bfly;
+template <int DIR> struct Bfly<1, DIR> { static FB_DEV void run(cf *) {} };
+template <int DIR> struct Bfly<2, DIR> { static FB_DEV void run(cf *v) { fft2<DIR>(v[0], v[1]); } };
+template <int DIR> struct Bfly<4, DIR> { static FB_DEV void run(cf *v) { fft4<DIR>(v[0], v[1], v[2], v[3]); } };
+template <int DIR> struct Bfly<8, DIR> {
+    static FB_DEV void run(cf *v)
+    {
+        fft4<DIR>(v[0], v[2], v[4], v[6]);            // even  -> E[k] in v[0],v[2],v[4],v[6]
+        fft4<DIR>(v[1], v[3], v[5], v[7]);            // odd   -> O[k] in v[1],v[3],v[5],v[7]
+        cf o1 = mul_w16<2, DIR>(v[3]), o2 = mul_w16<4, DIR>(v[5]), o3 = mul_w16<6, DIR>(v[7]);
+        cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+        v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+        v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+        v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+        v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+    }
+};
+template <int DIR> struct Bfly<16, DIR> {
+    static FB_DEV void run(cf *v)
+    {
+        // x[4 n1 + n2]: column n2 transformed over n1
+        fft4<DIR>(v[0], v[4], v[8], v[12]);
+        fft4<DIR>(v[1], v[5], v[9], v[13]);
+        fft4<DIR>(v[2], v[6], v[10], v[14]);
+        fft4<DIR>(v[3], v[7], v[11], v[15]);
+        // now v[4 k1 + n2] = Y_{n2}[k1]; twiddle W16^{n2 k1}
+        v[5]  = mul_w16<1, DIR>(v[5]);  v[6]  = mul_w16<2, DIR>(v[6]);  v[7]  = mul_w16<3, DIR>(v[7]);
+        v[9]  = mul_w16<2, DIR>(v[9]);  v[10] = mul_w16<4, DIR>(v[10]); v[11] = mul_w16<6, DIR>(v[11]);
+        v[13] = mul_w16<3, DIR>(v[13]); v[14] = mul_w16<6, DIR>(v[14]); v[15] = mul_w16<9, DIR>(v[15]);
+        // transform over n2 for each k1 -> X[k1 + 4 k2] lands in v[4 k1 + k2]
+        fft4<DIR>(v[0], v[1], v[2], v[3]);
+        fft4<DIR>(v[4], v[5], v[6], v[7]);
+        fft4<DIR>(v[8], v[9], v[10], v[11]);
+        fft4<DIR>(v[12], v[13], v[14], v[15]);
+        // transpose 4x4: want v[k1 + 4 k2]
+        cf t;
+        t = v[1];  v[1]  = v[4];  v[4]  = t;
+        t = v[2];  v[2]  = v[8];  v[8]  = t;
+        t = v[3];  v[3]  = v[12]; v[12] = t;
+        t = v[6];  v[6]  = v[9];  v[9]  = t;
+        t = v[7];  v[7]  = v[13]; v[13] = t;
+        t = v[11]; v[11] = v[14]; v[14] = t;
+    }
+};
+
+// ============================================================================================
+// Wave-tile FFT: one wave64 transforms 16 columns x n rows (n in 8..128) along the rows.
+//
+//  layout LA ("load"):  lane = (g = lane>>3, cp = lane&7); columns 2cp,2cp+1 (one float4);
+//                       rows r = g + 8 m, m < n/8
+//  layout LB ("freq"):  lane = (h = lane>>4, c = lane&15); column c; indices k = p + R1 q with
+//                       p = h + 4 s (s < NP), q < 8, R1 = n/8; lanes with h >= R1 idle if R1 < 4
+//  A2B: LA -> LB (radix-R1 in registers over m, twiddle W_n^{g p}, LDS exchange, radix-8 over g)
+//  B2A: LB -> LA (radix-8 over q, twiddle, LDS exchange, radix-R1 over p)
+//  LDS per wave: R1 * WT_PSTR complex.  Only the calling wave touches its region; DS
+//  instructions of one wave execute in order, so no barrier is required between phases.
+// ============================================================================================
+#define WT_PSTR 144   /* [p][g(8)][col(16)] + 16 complex pad: keeps the LB accesses conflict-free */
+
+template <int n> struct WaveTile {
+    static constexpr int R1 = n / 8;
+    static constexpr int NP = R1 >= 4 ? R1 / 4 : 1;
+    static constexpr int NLB = NP * 8;        // complex per lane in LB
+    static constexpr int NLA = n / 8;         // float4 per lane in LA
+    static constexpr int LDS_CF = R1 * WT_PSTR;
+    static FB_DEV bool lb_active(int lane) { return R1 >= 4 || (lane >> 4) < R1; }
+};
+
+template <int n, int DIR>
+FB_DEV void wave_fft_A2B(const float4 *in /*[n/8]*/, cf *out /*[NLB]*/, cf *lds, const cf *__restrict__ tw_n, int lane)
+{
+    constexpr int R1 = WaveTile<n>::R1, NP = WaveTile<n>::NP;
+    const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
+    cf a0[R1], a1[R1];
+#pragma unroll
+    for (int m = 0; m < R1; ++m) { a0[m] = cf_make(in[m].x, in[m].y); a1[m] = cf_make(in[m].z, in[m].w); }
+    Bfly<R1, DIR>::run(a0);
+    Bfly<R1, DIR>::run(a1);
+#pragma unroll
+    for (int p = 0; p < R1; ++p) {
+        if (p > 0) {
+            cf w = tw_n[g * p];
+            a0[p] = cmul_dir<DIR>(a0[p], w);
+            a1[p] = cmul_dir<DIR>(a1[p], w);
+        }
+        *reinterpret_cast<float4 *>(&lds[p * WT_PSTR + g * 16 + 2 * cp]) = make_float4(a0[p].x, a0[p].y, a1[p].x, a1[p].y);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (WaveTile<n>::lb_active(lane)) {
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const int p = h + 4 * s;
+            cf v[8];
+#pragma unroll
+            for (int gg = 0; gg < 8; ++gg) v[gg] = lds[p * WT_PSTR + gg * 16 + c];
+            Bfly<8, DIR>::run(v);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out[s * 8 + q] = v[q];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int n, int DIR>
+FB_DEV void wave_fft_B2A(const cf *in /*[NLB]*/, float4 *out /*[n/8]*/, cf *lds, const cf *__restrict__ tw_n, int lane)
+{
+    constexpr int R1 = WaveTile<n>::R1, NP = WaveTile<n>::NP;
+    const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
+    if (WaveTile<n>::lb_active(lane)) {
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const int p = h + 4 * s;
+            cf v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = in[s * 8 + q];
+            Bfly<8, DIR>::run(v);
+#pragma unroll
+            for (int gg = 0; gg < 8; ++gg) {
+                cf x = v[gg];
+                if (gg > 0) x = cmul_dir<DIR>(x, tw_n[p * gg]);
+                lds[p * WT_PSTR + gg * 16 + c] = x;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    cf a0[R1], a1[R1];
+#pragma unroll
+    for (int p = 0; p < R1; ++p) {
+        float4 t = *reinterpret_cast<const float4 *>(&lds[p * WT_PSTR + g * 16 + 2 * cp]);
+        a0[p] = cf_make(t.x, t.y); a1[p] = cf_make(t.z, t.w);
+    }
+    Bfly<R1, DIR>::run(a0);
+    Bfly<R1, DIR>::run(a1);
+#pragma unroll
+    for (int m = 0; m < R1; ++m) out[m] = make_float4(a0[m].x, a0[m].y, a1[m].x, a1[m].y);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ============================================================================================
+// Workgroup FFT in LDS (row pass): Stockham autosort, 16 elements per thread, radix 4/8/16
+// stages.  T = N/16 threads cooperate on one length-N FFT; element e lives at LDS slot
+// pad(e) = e + (e >> 4) so that both the strided reads and the scattered writes of every
+// stage are (nearly) bank-conflict free.
+//
+// Register distribution D_R after a last stage of radix R (and expected by a first stage of
+// radix R when fed from registers):  reg[m*R + q]  <->  position (t + m*T) + q*N/R.
+// ============================================================================================
+FB_DEV int lds_pad(int e) { return e + (e >> 4); }
+
+// One Stockham stage.  tw: stage table laid out [(m*(R-1) + (q-1))*T + t] (forward values).
+template <int N, int R, int NS, int DIR, bool FROM_REGS, bool TO_REGS>
+FB_DEV void stockham_stage(cf *lds, int t, const cf *__restrict__ tw, cf *reg /*[16]*/)
+{
+    constexpr int T = N / 16, NB = 16 / R, STR = N / R;
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+        const int j = t + m * T;
+        cf *v = reg + m * R;
+        if (!FROM_REGS) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[q] = lds[lds_pad(j + q * STR)];
+        }
+        if (NS > 1) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) v[q] = cmul_dir<DIR>(v[q], tw[(m * (R - 1) + (q - 1)) * T + t]);
+        }
+        Bfly<R, DIR>::run(v);
+    }
+    if (!TO_REGS) {
+        if (!FROM_REGS) __syncthreads();          // everyone has finished reading this buffer
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const int j = t + m * T;
+            const int j0 = (j / NS) * NS * R + (j % NS);
+#pragma unroll
+            for (int q = 0; q < R; ++q) lds[lds_pad(j0 + q * NS)] = reg[m * R + q];
+        }
+        __syncthreads();
+    }
+}
+
+// Row plans: radices of the BACKWARD (c2r) row transform; the forward transform uses them
+// reversed, so that the backward pass's final register distribution feeds the forward pass.
+template <int N> struct RowPlan;
+template <> struct RowPlan<64>    { static constexpr int S = 2; static constexpr int R[4] = {4, 16, 1, 1}; };
+template <> struct RowPlan<128>   { static constexpr int S = 2; static constexpr int R[4] = {8, 16, 1, 1}; };
+template <> struct RowPlan<256>   { static constexpr int S = 2; static constexpr int R[4] = {16, 16, 1, 1}; };
+template <> struct RowPlan<512>   { static constexpr int S = 3; static constexpr int R[4] = {4, 8, 16, 1}; };
+template <> struct RowPlan<1024>  { static constexpr int S = 3; static constexpr int R[4] = {8, 8, 16, 1}; };
+template <> struct RowPlan<2048>  { static constexpr int S = 3; static constexpr int R[4] = {8, 16, 16, 1}; };
+template <> struct RowPlan<4096>  { static constexpr int S = 3; static constexpr int R[4] = {16, 16, 16, 1}; };
+template <> struct RowPlan<8192>  { static constexpr int S = 4; static constexpr int R[4] = {4, 8, 16, 16}; };
+template <> struct RowPlan<16384> { static constexpr int S = 4; static constexpr int R[4] = {8, 8, 16, 16}; };
+
+// Twiddle table offsets (in complex elements) per stage for a plan walked in the given order.
+// Stage s (s >= 1) stores (16/R)*(R-1)*T entries; stage 0 has NS = 1 and stores nothing.
+template <int N, bool FWD> struct RowTw {
+    static constexpr int T = N / 16;
+    static constexpr int radix(int s) { return FWD ? RowPlan<N>::R[RowPlan<N>::S - 1 - s] : RowPlan<N>::R[s]; }
+    static constexpr int ns(int s) { int v = 1; for (int i = 0; i < s; ++i) v *= radix(i); return v; }
+    static constexpr int size(int s) { return s == 0 ? 0 : (16 / radix(s)) * (radix(s) - 1) * T; }
+    static constexpr int offset(int s) { int v = 0; for (int i = 0; i < s; ++i) v += size(i); return v; }
+    static constexpr int total() { return offset(RowPlan<N>::S); }
+};
+
+// Whole backward FFT: input in LDS (natural order, padded), output in registers (D_R, R = last radix).
+template <int N>
+FB_DEV void row_fft_bwd(cf *lds, int t, const cf *__restrict__ tw, cf *reg)
+{
+    using P = RowPlan<N>; using TW = RowTw<N, false>;
+    constexpr int S = P::S;
+    stockham_stage<N, TW::radix(0), 1, +1, false, false>(lds, t, tw, reg);
+    if constexpr (S == 2) {
+        stockham_stage<N, TW::radix(1), TW::ns(1), +1, false, true>(lds, t, tw + TW::offset(1), reg);
+    } else if constexpr (S == 3) {
+        stockham_stage<N, TW::radix(1), TW::ns(1), +1, false, false>(lds, t, tw + TW::offset(1), reg);
+        stockham_stage<N, TW::radix(2), TW::ns(2), +1, false, true>(lds, t, tw + TW::offset(2), reg);
+    } else {
+        stockham_stage<N, TW::radix(1), TW::ns(1), +1, false, false>(lds, t, tw + TW::offset(1), reg);
+        stockham_stage<N, TW::radix(2), TW::ns(2), +1, false, false>(lds, t, tw + TW::offset(2), reg);
+        stockham_stage<N, TW::radix(3), TW::ns(3), +1, false, true>(lds, t, tw + TW::offset(3), reg);
+    }
+}
+
+// Whole forward FFT: input in registers (D_R, R = first radix), output in LDS (natural order, padded).
+template <int N>
+FB_DEV void row_fft_fwd(cf *lds, int t, const cf *__restrict__ tw, cf *reg)
+{
+    using P = RowPlan<N>; using TW = RowTw<N, true>;
+    constexpr int S = P::S;
+    stockham_stage<N, TW::radix(0), 1, -1, true, false>(lds, t, tw, reg);
+    stockham_stage<N, TW::radix(1), TW::ns(1), -1, false, false>(lds, t, tw + TW::offset(1), reg);
+    if constexpr (S >= 3) stockham_stage<N, TW::radix(2), TW::ns(2), -1, false, false>(lds, t, tw + TW::offset(2), reg);
+    if constexpr (S >= 4) stockham_stage<N, TW::radix(3), TW::ns(3), -1, false, false>(lds, t, tw + TW::offset(3), reg);
+}

@@ -1,0 +1,492 @@
+// fb_kernels.h -- HIP kernels of the RK4 hot path (gfx950).
+//
+// Data layouts in HBM (all private to the engine; the C ABI converts at its boundary):
+//   "mixed"    arrays  T, W4[f]   : [row = x][col = ky], pitch P complex (P multiple of 16, >= ny/2+1,
+//                                   pad columns are zero and stay zero: every pass is linear)
+//   "spectral" arrays  ZA, ZB, ACC: [row = N2*c + d][col = ky], holding kx = c + N1*d  (nx = N1*N2)
+// The x-direction (column) transform of length nx is done as two sub-passes of lengths N1 and
+// N2 on wave tiles of 16 columns, so that every HBM access is a full 128-byte line:
+//   forward : k_col_strided<N1,-1> (over a; rows N2*a+b)  -> twiddle W_nx^{bc} -> block FFT over b
+//   backward: block FFT over d -> twiddle conj -> k_col_strided<N1,+1> (over c)
+// The block sub-passes of both directions, the viscous term, the dealiasing mask, the RK4 update
+// and the four spectral derivatives are fused in k_col_mid.
+// The y-direction (row) transforms, normalisation, sign of u and the Jacobian product are fused
+// in k_row<FUSED> (a7-a11).
+#pragma once
+#include "fb_fft_core.h"
+
+// -------------------------------------------------------------------------------------------
+// spectral coefficient tables (device): built once per context from fftwfop.cpp:15-24 values
+// -------------------------------------------------------------------------------------------
+struct SpecCoef {
+    const float  *gx;      // [nx]  gradx_coe                       fftwfop.cpp:15-20
+    const double *kx2;     // [nx]  (double)gradx_coe^2             fftwfop.cpp:42,45 (pow(float,int))
+    const float  *gy;      // [P]   grady_coe, zero in pad columns  fftwfop.cpp:22-24
+    const double *ky2;     // [P]
+    double gws;            // generalized_wavenumber_square         fftwfop.cpp:57
+    int nx, hy;            // hy = ny/2+1 (columns >= hy are padding)
+};
+
+// laplacian_coe[i][j] = (float)-(kx2 + ky2)                         fftwfop.cpp:45
+FB_DEV float coef_lap(const SpecCoef &c, int i, int j) { return (float)(-(c.kx2[i] + c.ky2[j])); }
+// dealiasing_mask                                                    fftwfop.cpp:57-68
+FB_DEV float coef_mask(const SpecCoef &c, int i, int j)
+{
+    int ii = i < c.nx - i ? i : c.nx - i;
+    double r2 = (double)ii * (double)ii + (double)j * (double)j;
+    return (r2 >= c.gws || j >= c.hy) ? 0.0f : 1.0f;
+}
+
+// -------------------------------------------------------------------------------------------
+// pointwise kernels of the standalone operator API (bit-exact float32 forms; no contraction)
+// -------------------------------------------------------------------------------------------
+enum { OP_GRADX = 0, OP_GRADY = 1, OP_LAP = 2, OP_INVLAP = 3, OP_DEALIAS = 4 };
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_spec_op(SpecCoef c, const cf *__restrict__ in, cf *__restrict__ out, int hy, size_t total)
+{
+#pragma clang fp contract(off)
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / hy), j = (int)(idx - (size_t)i * hy);
+        cf a = in[idx], r;
+        if (OP == OP_GRADX) { float k = c.gx[i]; r = cf_make(-a.y * k, a.x * k); }            // fftwfop.cpp:87-94
+        else if (OP == OP_GRADY) { float k = c.gy[j]; r = cf_make(-a.y * k, a.x * k); }       // :96-103
+        else if (OP == OP_LAP) { float k = coef_lap(c, i, j); r = cf_make(a.x * k, a.y * k); } // :105-110
+        else if (OP == OP_INVLAP) { float k = (i == 0 && j == 0) ? 1.0f : coef_lap(c, i, j);   // :112-117
+                                    r = cf_make(a.x / k, a.y / k); }
+        else { float k = coef_mask(c, i, j); r = cf_make(a.x * k, a.y * k); }                 // :119-124
+        out[idx] = r;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scale_real(float *d, float s, int divide, size_t n)
+{
+#pragma clang fp contract(off)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        d[i] = divide ? d[i] / s : d[i] * s;
+}
+
+// main.cpp:225-227   dvortdt = - u*dvortdx - v*dvortdy + vort_src
+__global__ void __launch_bounds__(256) k_jacobian(const float *__restrict__ u, const float *__restrict__ v,
+                                                  const float *__restrict__ dx, const float *__restrict__ dy,
+                                                  const float *__restrict__ src, float *__restrict__ out, size_t n)
+{
+#pragma clang fp contract(off)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = src ? src[i] : 0.0f;
+        out[i] = -u[i] * dx[i] - v[i] * dy[i] + s;
+    }
+}
+
+// mode 0: acc += x*a (main.cpp:240-243) ; mode 1: out = base + x*a (main.cpp:246-251)
+__global__ void __launch_bounds__(256) k_spec_axpy(const float *__restrict__ base, const float *__restrict__ x, float a,
+                                                   float *__restrict__ out, size_t n)
+{
+#pragma clang fp contract(off)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = base[i] + x[i] * a;
+}
+
+// main.cpp:309-312
+__global__ void __launch_bounds__(256) k_rk4_combine(const float *__restrict__ base, const float *__restrict__ k1,
+                                                     const float *__restrict__ k2, const float *__restrict__ k3,
+                                                     const float *__restrict__ k4, float dt, float *__restrict__ out, size_t n)
+{
+#pragma clang fp contract(off)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = base[i] + (k1[i] + 2.0f * k2[i] + 2.0f * k3[i] + k4[i]) * dt / 6.0f;
+}
+
+// natural half spectrum [kx][ky] pitch hy  <->  private spectral layout [N2*c+d][ky] pitch P
+template <bool TO_PRIVATE>
+__global__ void __launch_bounds__(256) k_spec_relayout(const cf *__restrict__ in, cf *__restrict__ out, int nx, int hy, int P, int N1, int N2)
+{
+    const size_t total = (size_t)nx * P;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / P), col = (int)(idx - (size_t)row * P);
+        const int c = row / N2, d = row - c * N2, kx = c + N1 * d;
+        if (TO_PRIVATE) out[idx] = col < hy ? in[(size_t)kx * hy + col] : cf_make(0.f, 0.f);
+        else if (col < hy) out[(size_t)kx * hy + col] = in[idx];
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// row pass (y direction), T = N/16 threads per transform, G = max(1, 256/T) row pairs per WG
+// -------------------------------------------------------------------------------------------
+enum { ROW_FUSED = 0, ROW_INV = 1, ROW_FWD = 2 };
+
+struct RowArgs {
+    const cf *M;            // mixed-space inputs, field f at M + f*m_fstride     (FUSED: 4 fields, INV: 1)
+    long m_fstride;         // complex elements
+    int  ks;                // columns per slab (== pitch P on one GPU)
+    long m_sstride;         // slab stride (complex), 0 on one GPU
+    cf  *T;                 // mixed-space output (FUSED, FWD)
+    long t_sstride;
+    const float *src;       // vort_src (real [x][y]) or NULL             (FUSED)
+    const float *rin;       // real input  [x][y]                          (FWD)
+    float *rout;            // real output [x][y]                          (INV)
+    int nx;                 // local rows (even)
+    float scale;            // 1/GRIDS (FUSED) ; 1/GRIDS or 1 (INV)
+    const cf *tw_bwd, *tw_fwd;
+};
+
+template <int N> struct RowCfg {
+    static constexpr int T = N / 16;
+    static constexpr int G = T >= 256 ? 1 : 256 / T;
+    static constexpr int THREADS = T * G;
+    static constexpr int LSTR = N + N / 16;               // padded complex per group
+    static constexpr size_t LDS_BYTES = (size_t)G * LSTR * sizeof(cf);
+};
+
+FB_DEV const cf *row_ptr(const cf *base, int ks, long sstride, int row, int k)
+{
+    if (sstride == 0) return base + (size_t)row * ks + k;
+    const int slab = k / ks;
+    return base + (size_t)slab * sstride + (size_t)row * ks + (k - slab * ks);
+}
+
+// Hermitian-extend two half-spectrum rows A,B into Z = A_ext + i B_ext in LDS (SURVEY note N2:
+// imaginary parts at k=0 and k=N/2 are ignored).
+template <int N>
+FB_DEV void row_load_pair(cf *lds, int t, const cf *baseA, const cf *baseB, int rowA, int rowB, int ks, long sstride)
+{
+    constexpr int T = N / 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = 2 * (t + T * i);
+        const float4 a = *reinterpret_cast<const float4 *>(row_ptr(baseA, ks, sstride, rowA, k));
+        const float4 b = *reinterpret_cast<const float4 *>(row_ptr(baseB, ks, sstride, rowB, k));
+        cf z0 = cf_make(a.x - b.y, a.y + b.x), z1 = cf_make(a.z - b.w, a.w + b.z);
+        cf m0 = cf_make(a.x + b.y, b.x - a.y), m1 = cf_make(a.z + b.w, b.z - a.w);
+        if (k == 0) z0 = cf_make(a.x, b.x);
+        lds[lds_pad(k)] = z0;
+        lds[lds_pad(k + 1)] = z1;
+        if (k != 0) lds[lds_pad(N - k)] = m0;
+        lds[lds_pad(N - k - 1)] = m1;
+    }
+    if (t == 0) {
+        const cf a = *row_ptr(baseA, ks, sstride, rowA, N / 2), b = *row_ptr(baseB, ks, sstride, rowB, N / 2);
+        lds[lds_pad(N / 2)] = cf_make(a.x, b.x);
+    }
+}
+
+// untangle Z = FFT(t0 + i t1) in LDS into the two half spectra and store rows rowA,rowB of T
+template <int N>
+FB_DEV void row_store_pair(const cf *lds, int t, cf *T, int rowA, int rowB, int ks, long sstride)
+{
+    constexpr int TT = N / 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = 2 * (t + TT * i);
+        const cf zk0 = lds[lds_pad(k)], zk1 = lds[lds_pad(k + 1)];
+        const cf zn0 = lds[lds_pad((N - k) & (N - 1))], zn1 = lds[lds_pad(N - k - 1)];
+        float4 A = make_float4(0.5f * (zk0.x + zn0.x), 0.5f * (zk0.y - zn0.y), 0.5f * (zk1.x + zn1.x), 0.5f * (zk1.y - zn1.y));
+        float4 B = make_float4(0.5f * (zk0.y + zn0.y), 0.5f * (zn0.x - zk0.x), 0.5f * (zk1.y + zn1.y), 0.5f * (zn1.x - zk1.x));
+        *reinterpret_cast<float4 *>(const_cast<cf *>(row_ptr(T, ks, sstride, rowA, k))) = A;
+        *reinterpret_cast<float4 *>(const_cast<cf *>(row_ptr(T, ks, sstride, rowB, k))) = B;
+    }
+    if (t == 0) {
+        const cf z = lds[lds_pad(N / 2)];
+        *const_cast<cf *>(row_ptr(T, ks, sstride, rowA, N / 2)) = cf_make(z.x, 0.f);
+        *const_cast<cf *>(row_ptr(T, ks, sstride, rowB, N / 2)) = cf_make(z.y, 0.f);
+    }
+}
+
+template <int N, int MODE>
+__global__ void __launch_bounds__(RowCfg<N>::THREADS) k_row(RowArgs a)
+{
+    using C = RowCfg<N>;
+    constexpr int T = C::T, G = C::G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *smem = reinterpret_cast<cf *>(smem_raw);
+    const int grp = threadIdx.x / T, t = threadIdx.x - grp * T;
+    cf *lds = smem + (size_t)grp * C::LSTR;
+    const int npairs = a.nx >> 1;
+    const int iters = (npairs + gridDim.x * G - 1) / (gridDim.x * G);
+
+    for (int it = 0; it < iters; ++it) {
+        const int pr = (it * gridDim.x + blockIdx.x) * G + grp;
+        const bool valid = pr < npairs;
+        const int x0 = valid ? 2 * pr : 0, x1 = x0 + 1;       // invalid groups recompute pair 0, store nothing
+        cf reg[16];
+        float t0[16], t1[16];
+
+        if (MODE == ROW_FUSED) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int x = r ? x1 : x0;
+                float zx[16], zy[16];
+                __syncthreads();
+                row_load_pair<N>(lds, t, a.M, a.M + a.m_fstride, x, x, a.ks, a.m_sstride);
+                __syncthreads();
+                row_fft_bwd<N>(lds, t, a.tw_bwd, reg);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { zx[q] = reg[q].x * a.scale; zy[q] = reg[q].y * a.scale; }   // main.cpp:154,168
+                __syncthreads();
+                row_load_pair<N>(lds, t, a.M + 2 * a.m_fstride, a.M + 3 * a.m_fstride, x, x, a.ks, a.m_sstride);
+                __syncthreads();
+                row_fft_bwd<N>(lds, t, a.tw_bwd, reg);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float u = -(reg[q].x * a.scale);            // main.cpp:200-201
+                    const float v = reg[q].y * a.scale;               // main.cpp:214
+                    const float s = a.src ? a.src[(size_t)x * N + t + q * T] : 0.0f;
+                    const float val = -u * zx[q] - v * zy[q] + s;     // main.cpp:225-227
+                    if (r == 0) t0[q] = val; else t1[q] = val;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) reg[q] = cf_make(t0[q], t1[q]);
+        } else if (MODE == ROW_FWD) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                reg[q] = cf_make(a.rin[(size_t)x0 * N + t + q * T], a.rin[(size_t)x1 * N + t + q * T]);
+        }
+
+        if (MODE == ROW_FUSED || MODE == ROW_FWD) {
+            row_fft_fwd<N>(lds, t, a.tw_fwd, reg);                    // main.cpp:237 (y part)
+            if (valid) row_store_pair<N>(lds, t, a.T, x0, x1, a.ks, a.t_sstride);
+        } else {
+            __syncthreads();
+            row_load_pair<N>(lds, t, a.M, a.M, x0, x1, a.ks, a.m_sstride);
+            __syncthreads();
+            row_fft_bwd<N>(lds, t, a.tw_bwd, reg);
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    a.rout[(size_t)x0 * N + t + q * T] = reg[q].x * a.scale;
+                    a.rout[(size_t)x1 * N + t + q * T] = reg[q].y * a.scale;
+                }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// column sub-passes on wave tiles (16 columns x n rows), 4 waves per workgroup
+// -------------------------------------------------------------------------------------------
+struct ColArgs {
+    cf *data;          // field f at data + f*fstride
+    long fstride;
+    int nfields;
+    int P;             // pitch (complex)
+    int N1, N2;        // nx = N1*N2
+    const cf *tw_n;    // W_n^j, j < n   (n = transform length of this kernel)
+    const cf *tw_big;  // W_nx^j, j < nx (block kernels)
+};
+
+// strided sub-pass: FFT of length n = N1 over a (rows N2*a + b), in place
+template <int n, int DIR>
+__global__ void __launch_bounds__(256) k_col_strided(ColArgs a)
+{
+    using W = WaveTile<n>;
+    __shared__ __attribute__((aligned(16))) cf smem[4 * W::LDS_CF];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    cf *lds = smem + wv * W::LDS_CF;
+    const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
+    const int ntc = a.P >> 4;
+    const long ntiles = (long)a.nfields * a.N2 * ntc;
+    for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const int f = (int)(tile / ((long)a.N2 * ntc));
+        const int rem = (int)(tile - (long)f * a.N2 * ntc);
+        const int b = rem / ntc, ct = rem - b * ntc;
+        cf *base = a.data + (size_t)f * a.fstride + (size_t)b * a.P + ct * 16;
+        float4 in[W::NLA];
+#pragma unroll
+        for (int m = 0; m < W::NLA; ++m)
+            in[m] = *reinterpret_cast<const float4 *>(base + (size_t)(g + 8 * m) * a.N2 * a.P + 2 * cp);
+        cf out[W::NLB];
+        wave_fft_A2B<n, DIR>(in, out, lds, a.tw_n, lane);
+        if (W::lb_active(lane)) {
+#pragma unroll
+            for (int s = 0; s < W::NP; ++s)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int k = h + 4 * s + W::R1 * q;
+                    base[(size_t)k * a.N2 * a.P + c] = out[s * 8 + q];
+                }
+        }
+    }
+}
+
+// block sub-pass: FFT of length n = N2 over the contiguous rows N2*cb + b, with the W_nx^{b cb}
+// twiddle (forward: on load; backward: conjugate on store), in place
+template <int n, int DIR>
+__global__ void __launch_bounds__(256) k_col_block(ColArgs a)
+{
+    using W = WaveTile<n>;
+    __shared__ __attribute__((aligned(16))) cf smem[4 * W::LDS_CF];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    cf *lds = smem + wv * W::LDS_CF;
+    const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
+    const int ntc = a.P >> 4;
+    const long ntiles = (long)a.nfields * a.N1 * ntc;
+    for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const int f = (int)(tile / ((long)a.N1 * ntc));
+        const int rem = (int)(tile - (long)f * a.N1 * ntc);
+        const int cb = rem / ntc, ct = rem - cb * ntc;
+        cf *base = a.data + (size_t)f * a.fstride + (size_t)cb * n * a.P + ct * 16;
+        if (DIR < 0) {
+            float4 in[W::NLA];
+#pragma unroll
+            for (int m = 0; m < W::NLA; ++m) {
+                const int b = g + 8 * m;
+                float4 v = *reinterpret_cast<const float4 *>(base + (size_t)b * a.P + 2 * cp);
+                const cf w = a.tw_big[b * cb];
+                cf p0 = cmul(cf_make(v.x, v.y), w), p1 = cmul(cf_make(v.z, v.w), w);
+                in[m] = make_float4(p0.x, p0.y, p1.x, p1.y);
+            }
+            cf out[W::NLB];
+            wave_fft_A2B<n, -1>(in, out, lds, a.tw_n, lane);
+            if (W::lb_active(lane)) {
+#pragma unroll
+                for (int s = 0; s < W::NP; ++s)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) base[(size_t)(h + 4 * s + W::R1 * q) * a.P + c] = out[s * 8 + q];
+            }
+        } else {
+            cf in[W::NLB];
+            if (W::lb_active(lane)) {
+#pragma unroll
+                for (int s = 0; s < W::NP; ++s)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) in[s * 8 + q] = base[(size_t)(h + 4 * s + W::R1 * q) * a.P + c];
+            }
+            float4 out[W::NLA];
+            wave_fft_B2A<n, +1>(in, out, lds, a.tw_n, lane);
+#pragma unroll
+            for (int m = 0; m < W::NLA; ++m) {
+                const int b = g + 8 * m;
+                const cf w = a.tw_big[b * cb];
+                cf p0 = cmulc(cf_make(out[m].x, out[m].y), w), p1 = cmulc(cf_make(out[m].z, out[m].w), w);
+                *reinterpret_cast<float4 *>(base + (size_t)b * a.P + 2 * cp) = make_float4(p0.x, p0.y, p1.x, p1.y);
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// fused middle kernel: [forward block sub-pass of the tendency] + viscous term + mask + RK4
+// update + the four spectral derivatives + [backward block sub-pass of each]
+// -------------------------------------------------------------------------------------------
+struct MidArgs {
+    const cf *Tin;       // tendency after the strided forward sub-pass (mixed/partial layout)
+    const cf *Zbase;     // vort_c0 of this step                    (private spectral layout)
+    cf *Zcur;            // vort_c of this stage; updated in place (stage 0: written only)
+    cf *Acc;             // running rk1 + 2 rk2 + 2 rk3
+    cf *Zout;            // stage 3: new vort_c is written here (== Zbase's buffer)
+    cf *W4;              // four derived fields, field f at W4 + f*fstride
+    long fstride;
+    int P, N1, N2;
+    int ky0;             // global ky of local column 0 (slab offset)
+    int stage;           // 0..3 RK stage whose tendency arrives; -1 = derive only (prime the pipeline)
+    float nu, dt;
+    SpecCoef coef;
+    const cf *tw_n, *tw_big;
+};
+
+template <int n>
+__global__ void __launch_bounds__(256) k_col_mid(MidArgs a)
+{
+    using W = WaveTile<n>;
+    __shared__ __attribute__((aligned(16))) cf smem[4 * W::LDS_CF];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    cf *lds = smem + wv * W::LDS_CF;
+    const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
+    const int ntc = a.P >> 4;
+    const long ntiles = (long)a.N1 * ntc;
+    const bool lb = W::lb_active(lane);
+    for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const int cb = (int)(tile / ntc), ct = (int)(tile - (long)cb * ntc);
+        const size_t tbase = (size_t)cb * n * a.P + ct * 16;
+        cf wbig[W::NLA];
+#pragma unroll
+        for (int m = 0; m < W::NLA; ++m) wbig[m] = a.tw_big[(g + 8 * m) * cb];
+
+        cf zn[W::NLB];                       // state the derivatives are taken of (LB layout)
+        const int col = ct * 16 + c, ky = a.ky0 + col;
+        const float gy = a.coef.gy[ky];
+        const double ky2 = a.coef.ky2[ky];
+
+        if (a.stage >= 0) {
+            float4 in[W::NLA];
+#pragma unroll
+            for (int m = 0; m < W::NLA; ++m) {
+                float4 v = *reinterpret_cast<const float4 *>(a.Tin + tbase + (size_t)(g + 8 * m) * a.P + 2 * cp);
+                cf p0 = cmul(cf_make(v.x, v.y), wbig[m]), p1 = cmul(cf_make(v.z, v.w), wbig[m]);
+                in[m] = make_float4(p0.x, p0.y, p1.x, p1.y);
+            }
+            cf th[W::NLB];
+            wave_fft_A2B<n, -1>(in, th, lds, a.tw_n, lane);               // main.cpp:237 (x part)
+            if (lb) {
+#pragma unroll
+                for (int s = 0; s < W::NP; ++s)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = s * 8 + q, d = h + 4 * s + W::R1 * q, ikx = cb + a.N1 * d;
+                        const size_t off = tbase + (size_t)d * a.P + c;
+                        const float lap = (float)(-(a.coef.kx2[ikx] + ky2));
+                        const float msk = coef_mask(a.coef, ikx, ky);
+                        const cf z0 = a.Zbase[off];
+                        const cf zc = a.stage == 0 ? z0 : a.Zcur[off];
+                        // dvortdt_c += lvort_c * NU ; rk = dealiase(dvortdt_c)   main.cpp:148,240-243,296
+                        cf k = cf_make((th[e].x + (zc.x * lap) * a.nu) * msk, (th[e].y + (zc.y * lap) * a.nu) * msk);
+                        cf acc, znew;
+                        if (a.stage == 0) {            // main.cpp:296
+                            acc = k; znew = cf_make(z0.x + k.x * (a.dt / 2.0f), z0.y + k.y * (a.dt / 2.0f));
+                        } else if (a.stage == 1) {     // main.cpp:299
+                            const cf ac = a.Acc[off];
+                            acc = cf_make(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y);
+                            znew = cf_make(z0.x + k.x * (a.dt / 2.0f), z0.y + k.y * (a.dt / 2.0f));
+                        } else if (a.stage == 2) {     // main.cpp:302
+                            const cf ac = a.Acc[off];
+                            acc = cf_make(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y);
+                            znew = cf_make(z0.x + k.x * a.dt, z0.y + k.y * a.dt);
+                        } else {                       // main.cpp:309-312
+                            const cf ac = a.Acc[off];
+                            acc = ac;
+                            znew = cf_make(z0.x + (ac.x + k.x) * a.dt / 6.0f, z0.y + (ac.y + k.y) * a.dt / 6.0f);
+                        }
+                        if (a.stage < 3) { a.Acc[off] = acc; a.Zcur[off] = znew; }
+                        else a.Zout[off] = znew;
+                        zn[e] = znew;
+                    }
+            }
+        } else if (lb) {
+#pragma unroll
+            for (int s = 0; s < W::NP; ++s)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    zn[s * 8 + q] = a.Zbase[tbase + (size_t)(h + 4 * s + W::R1 * q) * a.P + c];
+        }
+
+        // four derivatives of zn, each through the backward block sub-pass
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            cf fld[W::NLB];
+            if (lb) {
+#pragma unroll
+                for (int s = 0; s < W::NP; ++s)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = s * 8 + q, d = h + 4 * s + W::R1 * q, ikx = cb + a.N1 * d;
+                        cf z = zn[e];
+                        if (f >= 2) {          // psi_c = invertLaplacian(vort_c)   main.cpp:179, fftwfop.cpp:112-117
+                            const float li = (ikx == 0 && ky == 0) ? 1.0f : (float)(-(a.coef.kx2[ikx] + ky2));
+                            z = (ky < a.coef.hy) ? cf_make(z.x / li, z.y / li) : cf_make(0.f, 0.f);
+                        }
+                        const float kk = (f == 0 || f == 3) ? a.coef.gx[ikx] : gy;   // f0 gradx(vort) f1 grady(vort) f2 grady(psi) f3 gradx(psi)
+                        fld[e] = cf_make(-z.y * kk, z.x * kk);                        // fftwfop.cpp:87-103
+                    }
+            }
+            float4 out[W::NLA];
+            wave_fft_B2A<n, +1>(fld, out, lds, a.tw_n, lane);
+            cf *dst = a.W4 + (size_t)f * a.fstride + tbase;
+#pragma unroll
+            for (int m = 0; m < W::NLA; ++m) {
+                cf p0 = cmulc(cf_make(out[m].x, out[m].y), wbig[m]), p1 = cmulc(cf_make(out[m].z, out[m].w), wbig[m]);
+                *reinterpret_cast<float4 *>(dst + (size_t)(g + 8 * m) * a.P + 2 * cp) = make_float4(p0.x, p0.y, p1.x, p1.y);
+            }
+        }
+    }
+}

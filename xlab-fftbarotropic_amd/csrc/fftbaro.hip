@@ -1,0 +1,673 @@
+// fftbaro.hip -- C ABI (include/fftbaro.h) of the MI355X-native barotropic-vorticity engine.
+// Host side: context/plan/tables, launch logic, model state machine.  Kernels: fb_kernels.h.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fftbaro.h"
+#include "fb_kernels.h"
+
+// --------------------------------------------------------------------------------------------
+// errors
+// --------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(FB_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+extern "C" const char *fb_strerror(int s)
+{
+    switch (s) {
+    case FB_OK: return "ok";
+    case FB_EINVAL: return "invalid argument";
+    case FB_ENOMEM: return "out of memory";
+    case FB_EHIP: return "HIP runtime error";
+    case FB_EIO: return "I/O error";
+    case FB_EUNSUPPORTED: return "unsupported grid size";
+    default: return "unknown status";
+    }
+}
+extern "C" const char *fb_last_error(void) { return g_last_error.c_str(); }
+extern "C" int fb_version(void) { return 100; }
+
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+extern "C" int fb_size_supported(int nx, int ny)
+{
+    return is_pow2(nx) && is_pow2(ny) && nx >= 64 && nx <= 16384 && ny >= 64 && ny <= 16384;
+}
+
+// --------------------------------------------------------------------------------------------
+// context
+// --------------------------------------------------------------------------------------------
+struct fb_ctx {
+    int nx, ny, hy, P;          // P = pitch of the private layouts (complex)
+    int N1, N2;                 // nx = N1*N2
+    float lx, ly;
+    hipStream_t stream;
+    // device tables
+    float *d_gx; double *d_kx2; float *d_gy; double *d_ky2; double gws;
+    cf *d_tw_n1, *d_tw_n2, *d_tw_big, *d_tw_row_bwd, *d_tw_row_fwd;
+    cf *d_scratch;              // nx*P complex, lazily allocated (standalone r2c / c2r)
+    // host copies of the 1-D tables (fb_get_tables)
+    std::vector<float> h_gx, h_gy; std::vector<double> h_kx2, h_ky2;
+    int max_wg;                 // grid cap (persistent-style grids)
+};
+
+static void split_nx(int nx, int &N1, int &N2)
+{
+    switch (nx) {
+    case 64: N1 = 8; N2 = 8; break;
+    case 128: N1 = 16; N2 = 8; break;
+    case 256: N1 = 16; N2 = 16; break;
+    case 512: N1 = 32; N2 = 16; break;
+    case 1024: N1 = 32; N2 = 32; break;
+    case 2048: N1 = 64; N2 = 32; break;
+    case 4096: N1 = 64; N2 = 64; break;
+    case 8192: N1 = 128; N2 = 64; break;
+    default: N1 = 128; N2 = 128; break;   // 16384
+    }
+}
+
+static std::vector<cf> make_root_table(int n)
+{
+    std::vector<cf> t(n);
+    for (int j = 0; j < n; ++j) {
+        double a = -2.0 * M_PI * (double)j / (double)n;
+        t[j].x = (float)cos(a); t[j].y = (float)sin(a);
+    }
+    return t;
+}
+
+// Stockham stage tables for a radix list walked in order (forward-sign values); layout must
+// match stockham_stage(): offset(s) + (m*(R-1) + (q-1))*T + t
+static std::vector<cf> make_row_table(int n, const std::vector<int> &radices)
+{
+    const int T = n / 16;
+    std::vector<cf> t;
+    int NS = 1;
+    for (size_t s = 0; s < radices.size(); ++s) {
+        const int R = radices[s];
+        if (s > 0) {
+            const int NB = 16 / R;
+            for (int m = 0; m < NB; ++m)
+                for (int q = 1; q < R; ++q)
+                    for (int tt = 0; tt < T; ++tt) {
+                        const int j = tt + m * T, k = j % NS;
+                        double a = -2.0 * M_PI * (double)k * (double)q / ((double)NS * (double)R);
+                        cf w; w.x = (float)cos(a); w.y = (float)sin(a);
+                        t.push_back(w);
+                    }
+        }
+        NS *= R;
+    }
+    return t;
+}
+
+template <int N> static std::vector<int> plan_radices(bool fwd)
+{
+    std::vector<int> r;
+    for (int s = 0; s < RowPlan<N>::S; ++s) r.push_back(RowTw<N, false>::radix(s));
+    if (fwd) r = std::vector<int>(r.rbegin(), r.rend());
+    return r;
+}
+
+static std::vector<int> plan_radices_rt(int n, bool fwd)
+{
+    switch (n) {
+    case 64: return plan_radices<64>(fwd);
+    case 128: return plan_radices<128>(fwd);
+    case 256: return plan_radices<256>(fwd);
+    case 512: return plan_radices<512>(fwd);
+    case 1024: return plan_radices<1024>(fwd);
+    case 2048: return plan_radices<2048>(fwd);
+    case 4096: return plan_radices<4096>(fwd);
+    case 8192: return plan_radices<8192>(fwd);
+    default: return plan_radices<16384>(fwd);
+    }
+}
+
+template <typename T> static int upload(T **dptr, const std::vector<T> &h)
+{
+    HIPCHK(hipMalloc((void **)dptr, h.size() * sizeof(T)));
+    HIPCHK(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return FB_OK;
+}
+
+extern "C" int fb_create(fb_ctx **out, int nx, int ny, float lx, float ly)
+{
+    if (!out) return fail(FB_EINVAL, "fb_create: out is NULL");
+    *out = nullptr;
+    if (!fb_size_supported(nx, ny))
+        return fail(FB_EUNSUPPORTED, "fb_create: nx, ny must be powers of two in [64, 16384]");
+    if (!(lx > 0.f) || !(ly > 0.f)) return fail(FB_EINVAL, "fb_create: Lx, Ly must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FB_EHIP, "fb_create: no HIP device (this engine has no CPU fallback)");
+
+    fb_ctx *c = new fb_ctx();
+    c->nx = nx; c->ny = ny; c->hy = ny / 2 + 1; c->P = (c->hy + 15) / 16 * 16;
+    split_nx(nx, c->N1, c->N2);
+    c->lx = lx; c->ly = ly; c->stream = nullptr; c->d_scratch = nullptr;
+
+    // ---- coefficient tables: fftwfop.cpp:5-79 ----
+    const float TWOPI = (float)(acosf(-1.0f) * 2.0f);                  // fftwfop.hpp:7
+    const int hx = nx / 2 + 1;
+    c->h_gx.assign(nx, 0.f); c->h_kx2.assign(nx, 0.0); c->h_gy.assign(c->P, 0.f); c->h_ky2.assign(c->P, 0.0);
+    for (int i = 0; i < hx; ++i) c->h_gx[i] = TWOPI * ((float)i) / lx;            // :15-17
+    for (int i = hx; i < nx; ++i) c->h_gx[i] = -c->h_gx[nx - i];                  // :18-20
+    for (int j = 0; j < c->hy; ++j) c->h_gy[j] = TWOPI * ((float)j) / ly;         // :22-24
+    for (int i = 0; i < nx; ++i) c->h_kx2[i] = (double)c->h_gx[i] * (double)c->h_gx[i];
+    for (int j = 0; j < c->hy; ++j) c->h_ky2[j] = (double)c->h_gy[j] * (double)c->h_gy[j];
+    const int dxw = (int)ceil(((double)(float)nx) / 3.0), dyw = (int)ceil(((double)(float)ny) / 3.0);   // :11-12
+    c->gws = (double)(float)((double)dxw * dxw + (double)dyw * dyw);              // :57
+
+    int rc;
+    if ((rc = upload(&c->d_gx, c->h_gx)) || (rc = upload(&c->d_kx2, c->h_kx2)) ||
+        (rc = upload(&c->d_gy, c->h_gy)) || (rc = upload(&c->d_ky2, c->h_ky2)) ||
+        (rc = upload(&c->d_tw_n1, make_root_table(c->N1))) || (rc = upload(&c->d_tw_n2, make_root_table(c->N2))) ||
+        (rc = upload(&c->d_tw_big, make_root_table(nx))) ||
+        (rc = upload(&c->d_tw_row_bwd, make_row_table(ny, plan_radices_rt(ny, false)))) ||
+        (rc = upload(&c->d_tw_row_fwd, make_row_table(ny, plan_radices_rt(ny, true))))) {
+        delete c; return rc;
+    }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, 0));
+    c->max_wg = prop.multiProcessorCount * 8;
+    *out = c;
+    return FB_OK;
+}
+
+extern "C" int fb_destroy(fb_ctx *c)
+{
+    if (!c) return FB_OK;
+    hipFree(c->d_gx); hipFree(c->d_kx2); hipFree(c->d_gy); hipFree(c->d_ky2);
+    hipFree(c->d_tw_n1); hipFree(c->d_tw_n2); hipFree(c->d_tw_big); hipFree(c->d_tw_row_bwd); hipFree(c->d_tw_row_fwd);
+    if (c->d_scratch) hipFree(c->d_scratch);
+    delete c;
+    return FB_OK;
+}
+
+extern "C" int fb_set_stream(fb_ctx *c, void *s) { if (!c) return fail(FB_EINVAL, "ctx NULL"); c->stream = (hipStream_t)s; return FB_OK; }
+extern "C" int fb_synchronize(fb_ctx *c) { if (!c) return fail(FB_EINVAL, "ctx NULL"); HIPCHK(hipStreamSynchronize(c->stream)); return FB_OK; }
+
+static SpecCoef make_coef(const fb_ctx *c)
+{
+    SpecCoef s; s.gx = c->d_gx; s.kx2 = c->d_kx2; s.gy = c->d_gy; s.ky2 = c->d_ky2; s.gws = c->gws; s.nx = c->nx; s.hy = c->hy;
+    return s;
+}
+
+extern "C" int fb_get_tables(fb_ctx *c, float *gx, float *gy, float *lap, float *lapi, float *mask)
+{
+    if (!c) return fail(FB_EINVAL, "ctx NULL");
+    const int nx = c->nx, hy = c->hy;
+    if (gx) memcpy(gx, c->h_gx.data(), sizeof(float) * nx);
+    if (gy) memcpy(gy, c->h_gy.data(), sizeof(float) * hy);
+    for (int i = 0; i < nx; ++i)
+        for (int j = 0; j < hy; ++j) {
+            const size_t k = (size_t)i * hy + j;
+            const float l = (float)(-(c->h_kx2[i] + c->h_ky2[j]));
+            if (lap) lap[k] = l;
+            if (lapi) lapi[k] = (i == 0 && j == 0) ? 1.0f : l;
+            if (mask) {
+                const int ii = i < nx - i ? i : nx - i;
+                mask[k] = ((double)ii * ii + (double)j * j >= c->gws) ? 0.0f : 1.0f;
+            }
+        }
+    return FB_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// buffers
+// --------------------------------------------------------------------------------------------
+extern "C" int fb_malloc(void **p, size_t bytes)
+{
+    if (!p) return fail(FB_EINVAL, "fb_malloc: NULL");
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) return fail(FB_ENOMEM, "hipMalloc: out of memory");
+    HIPCHK(e);
+    return FB_OK;
+}
+extern "C" int fb_free(void *p) { if (p) HIPCHK(hipFree(p)); return FB_OK; }
+extern "C" int fb_memcpy_h2d(fb_ctx *c, void *d, const void *h, size_t n)
+{
+    if (!c || !d || !h) return fail(FB_EINVAL, "fb_memcpy_h2d: NULL");
+    HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return FB_OK;
+}
+extern "C" int fb_memcpy_d2h(fb_ctx *c, void *h, const void *d, size_t n)
+{
+    if (!c || !d || !h) return fail(FB_EINVAL, "fb_memcpy_d2h: NULL");
+    HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return FB_OK;
+}
+extern "C" int fb_memset0(fb_ctx *c, void *d, size_t n)
+{
+    if (!c || !d) return fail(FB_EINVAL, "fb_memset0: NULL");
+    HIPCHK(hipMemsetAsync(d, 0, n, c->stream)); return FB_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// pointwise launches
+// --------------------------------------------------------------------------------------------
+static int grid_for(const fb_ctx *c, size_t n, int block = 256)
+{
+    size_t g = (n + block - 1) / block;
+    if (g > (size_t)c->max_wg) g = c->max_wg;
+    return (int)(g ? g : 1);
+}
+
+template <int OP> static int launch_op(fb_ctx *c, const float *in, float *out)
+{
+    if (!c || !in || !out) return fail(FB_EINVAL, "operator: NULL argument");
+    const size_t total = (size_t)c->nx * c->hy;
+    hipLaunchKernelGGL((k_spec_op<OP>), dim3(grid_for(c, total)), dim3(256), 0, c->stream, make_coef(c), (const cf *)in, (cf *)out, c->hy, total);
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+extern "C" int fb_gradx(fb_ctx *c, const float *i, float *o) { return launch_op<OP_GRADX>(c, i, o); }
+extern "C" int fb_grady(fb_ctx *c, const float *i, float *o) { return launch_op<OP_GRADY>(c, i, o); }
+extern "C" int fb_laplacian(fb_ctx *c, const float *i, float *o) { return launch_op<OP_LAP>(c, i, o); }
+extern "C" int fb_invert_laplacian(fb_ctx *c, const float *i, float *o) { return launch_op<OP_INVLAP>(c, i, o); }
+extern "C" int fb_dealiase(fb_ctx *c, const float *i, float *o) { return launch_op<OP_DEALIAS>(c, i, o); }
+
+extern "C" int fb_backward_normalize(fb_ctx *c, float *d)
+{
+    if (!c || !d) return fail(FB_EINVAL, "fb_backward_normalize: NULL");
+    const size_t n = (size_t)c->nx * c->ny;
+    hipLaunchKernelGGL(k_scale_real, dim3(grid_for(c, n)), dim3(256), 0, c->stream, d, (float)(int)n, 1, n);
+    HIPCHK(hipGetLastError()); return FB_OK;
+}
+extern "C" int fb_negate(fb_ctx *c, float *d)
+{
+    if (!c || !d) return fail(FB_EINVAL, "fb_negate: NULL");
+    const size_t n = (size_t)c->nx * c->ny;
+    hipLaunchKernelGGL(k_scale_real, dim3(grid_for(c, n)), dim3(256), 0, c->stream, d, -1.0f, 0, n);
+    HIPCHK(hipGetLastError()); return FB_OK;
+}
+extern "C" int fb_jacobian(fb_ctx *c, const float *u, const float *v, const float *dx, const float *dy, const float *src, float *out)
+{
+    if (!c || !u || !v || !dx || !dy || !out) return fail(FB_EINVAL, "fb_jacobian: NULL");
+    const size_t n = (size_t)c->nx * c->ny;
+    hipLaunchKernelGGL(k_jacobian, dim3(grid_for(c, n)), dim3(256), 0, c->stream, u, v, dx, dy, src, out, n);
+    HIPCHK(hipGetLastError()); return FB_OK;
+}
+extern "C" int fb_spec_axpy(fb_ctx *c, float *acc, const float *x, float a)
+{
+    if (!c || !acc || !x) return fail(FB_EINVAL, "fb_spec_axpy: NULL");
+    const size_t n = 2 * (size_t)c->nx * c->hy;
+    hipLaunchKernelGGL(k_spec_axpy, dim3(grid_for(c, n)), dim3(256), 0, c->stream, (const float *)acc, x, a, acc, n);
+    HIPCHK(hipGetLastError()); return FB_OK;
+}
+extern "C" int fb_spec_evolve(fb_ctx *c, const float *base, const float *rk, float a, float *out)
+{
+    if (!c || !base || !rk || !out) return fail(FB_EINVAL, "fb_spec_evolve: NULL");
+    const size_t n = 2 * (size_t)c->nx * c->hy;
+    hipLaunchKernelGGL(k_spec_axpy, dim3(grid_for(c, n)), dim3(256), 0, c->stream, base, rk, a, out, n);
+    HIPCHK(hipGetLastError()); return FB_OK;
+}
+extern "C" int fb_spec_rk4_combine(fb_ctx *c, const float *base, const float *k1, const float *k2, const float *k3,
+                                   const float *k4, float dt, float *out)
+{
+    if (!c || !base || !k1 || !k2 || !k3 || !k4 || !out) return fail(FB_EINVAL, "fb_spec_rk4_combine: NULL");
+    const size_t n = 2 * (size_t)c->nx * c->hy;
+    hipLaunchKernelGGL(k_rk4_combine, dim3(grid_for(c, n)), dim3(256), 0, c->stream, base, k1, k2, k3, k4, dt, out, n);
+    HIPCHK(hipGetLastError()); return FB_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// FFT pass launchers
+// --------------------------------------------------------------------------------------------
+template <int N, int MODE> static int launch_row_t(fb_ctx *c, const RowArgs &a)
+{
+    using C = RowCfg<N>;
+    const int npairs = a.nx / 2;
+    int grid = (npairs + C::G - 1) / C::G;
+    const int cap = c->max_wg / 2;            // ~4 resident workgroups per CU
+    if (grid > cap) grid = cap;
+    auto kern = k_row<N, MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
+template <int MODE> static int launch_row(fb_ctx *c, const RowArgs &a)
+{
+    switch (c->ny) {
+    case 64: return launch_row_t<64, MODE>(c, a);
+    case 128: return launch_row_t<128, MODE>(c, a);
+    case 256: return launch_row_t<256, MODE>(c, a);
+    case 512: return launch_row_t<512, MODE>(c, a);
+    case 1024: return launch_row_t<1024, MODE>(c, a);
+    case 2048: return launch_row_t<2048, MODE>(c, a);
+    case 4096: return launch_row_t<4096, MODE>(c, a);
+    case 8192: return launch_row_t<8192, MODE>(c, a);
+    case 16384: return launch_row_t<16384, MODE>(c, a);
+    }
+    return fail(FB_EUNSUPPORTED, "row pass: unsupported ny");
+}
+
+static int col_grid(const fb_ctx *c, long ntiles)
+{
+    long g = (ntiles + 3) / 4;
+    if (g > c->max_wg) g = c->max_wg;
+    return (int)(g ? g : 1);
+}
+
+template <int DIR> static int launch_col_strided(fb_ctx *c, cf *data, int nfields, long fstride)
+{
+    ColArgs a; a.data = data; a.fstride = fstride; a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
+    a.tw_n = c->d_tw_n1; a.tw_big = c->d_tw_big;
+    const long ntiles = (long)nfields * c->N2 * (c->P / 16);
+    const dim3 g(col_grid(c, ntiles)), b(256);
+    switch (c->N1) {
+    case 8: hipLaunchKernelGGL((k_col_strided<8, DIR>), g, b, 0, c->stream, a); break;
+    case 16: hipLaunchKernelGGL((k_col_strided<16, DIR>), g, b, 0, c->stream, a); break;
+    case 32: hipLaunchKernelGGL((k_col_strided<32, DIR>), g, b, 0, c->stream, a); break;
+    case 64: hipLaunchKernelGGL((k_col_strided<64, DIR>), g, b, 0, c->stream, a); break;
+    case 128: hipLaunchKernelGGL((k_col_strided<128, DIR>), g, b, 0, c->stream, a); break;
+    default: return fail(FB_EUNSUPPORTED, "col strided: N1");
+    }
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
+template <int DIR> static int launch_col_block(fb_ctx *c, cf *data, int nfields, long fstride)
+{
+    ColArgs a; a.data = data; a.fstride = fstride; a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
+    a.tw_n = c->d_tw_n2; a.tw_big = c->d_tw_big;
+    const long ntiles = (long)nfields * c->N1 * (c->P / 16);
+    const dim3 g(col_grid(c, ntiles)), b(256);
+    switch (c->N2) {
+    case 8: hipLaunchKernelGGL((k_col_block<8, DIR>), g, b, 0, c->stream, a); break;
+    case 16: hipLaunchKernelGGL((k_col_block<16, DIR>), g, b, 0, c->stream, a); break;
+    case 32: hipLaunchKernelGGL((k_col_block<32, DIR>), g, b, 0, c->stream, a); break;
+    case 64: hipLaunchKernelGGL((k_col_block<64, DIR>), g, b, 0, c->stream, a); break;
+    case 128: hipLaunchKernelGGL((k_col_block<128, DIR>), g, b, 0, c->stream, a); break;
+    default: return fail(FB_EUNSUPPORTED, "col block: N2");
+    }
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
+static int launch_col_mid(fb_ctx *c, const MidArgs &a)
+{
+    const long ntiles = (long)c->N1 * (c->P / 16);
+    const dim3 g(col_grid(c, ntiles)), b(256);
+    switch (c->N2) {
+    case 8: hipLaunchKernelGGL((k_col_mid<8>), g, b, 0, c->stream, a); break;
+    case 16: hipLaunchKernelGGL((k_col_mid<16>), g, b, 0, c->stream, a); break;
+    case 32: hipLaunchKernelGGL((k_col_mid<32>), g, b, 0, c->stream, a); break;
+    case 64: hipLaunchKernelGGL((k_col_mid<64>), g, b, 0, c->stream, a); break;
+    case 128: hipLaunchKernelGGL((k_col_mid<128>), g, b, 0, c->stream, a); break;
+    default: return fail(FB_EUNSUPPORTED, "col mid: N2");
+    }
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
+static size_t priv_elems(const fb_ctx *c) { return (size_t)c->nx * c->P; }
+
+static int ensure_scratch(fb_ctx *c)
+{
+    if (!c->d_scratch) {
+        hipError_t e = hipMalloc((void **)&c->d_scratch, priv_elems(c) * sizeof(cf));
+        if (e != hipSuccess) return fail(FB_ENOMEM, "scratch allocation failed");
+    }
+    return FB_OK;
+}
+
+static RowArgs row_args_base(const fb_ctx *c)
+{
+    RowArgs a; memset(&a, 0, sizeof(a));
+    a.ks = c->P; a.m_sstride = 0; a.t_sstride = 0; a.nx = c->nx; a.tw_bwd = c->d_tw_row_bwd; a.tw_fwd = c->d_tw_row_fwd;
+    return a;
+}
+
+// real [nx][ny] -> private spectral layout (dst: nx*P complex, pad columns must be zero-initialised)
+static int r2c_private(fb_ctx *c, const float *d_real, cf *dst)
+{
+    RowArgs a = row_args_base(c); a.rin = d_real; a.T = dst;
+    int rc;
+    if ((rc = launch_row<ROW_FWD>(c, a))) return rc;
+    if ((rc = launch_col_strided<-1>(c, dst, 1, 0))) return rc;
+    return launch_col_block<-1>(c, dst, 1, 0);
+}
+
+// private spectral layout (work: destroyed) -> real [nx][ny] * scale
+static int c2r_private(fb_ctx *c, cf *work, float *d_real, float scale)
+{
+    int rc;
+    if ((rc = launch_col_block<+1>(c, work, 1, 0))) return rc;
+    if ((rc = launch_col_strided<+1>(c, work, 1, 0))) return rc;
+    RowArgs a = row_args_base(c); a.M = work; a.rout = d_real; a.scale = scale;
+    return launch_row<ROW_INV>(c, a);
+}
+
+static int relayout(fb_ctx *c, const cf *in, cf *out, bool to_private)
+{
+    const size_t total = priv_elems(c);
+    if (to_private) hipLaunchKernelGGL((k_spec_relayout<true>), dim3(grid_for(c, total)), dim3(256), 0, c->stream, in, out, c->nx, c->hy, c->P, c->N1, c->N2);
+    else hipLaunchKernelGGL((k_spec_relayout<false>), dim3(grid_for(c, total)), dim3(256), 0, c->stream, in, out, c->nx, c->hy, c->P, c->N1, c->N2);
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
+extern "C" int fb_r2c(fb_ctx *c, const float *d_in, float *d_out)
+{
+    if (!c || !d_in || !d_out) return fail(FB_EINVAL, "fb_r2c: NULL");
+    int rc;
+    if ((rc = ensure_scratch(c))) return rc;
+    HIPCHK(hipMemsetAsync(c->d_scratch, 0, priv_elems(c) * sizeof(cf), c->stream));
+    if ((rc = r2c_private(c, d_in, c->d_scratch))) return rc;
+    return relayout(c, c->d_scratch, (cf *)d_out, false);
+}
+
+extern "C" int fb_c2r(fb_ctx *c, const float *d_in, float *d_out, int normalize)
+{
+    if (!c || !d_in || !d_out) return fail(FB_EINVAL, "fb_c2r: NULL");
+    int rc;
+    if ((rc = ensure_scratch(c))) return rc;
+    if ((rc = relayout(c, (const cf *)d_in, c->d_scratch, true))) return rc;
+    const float scale = normalize ? 1.0f / (float)((size_t)c->nx * c->ny) : 1.0f;
+    return c2r_private(c, c->d_scratch, d_out, scale);
+}
+
+// --------------------------------------------------------------------------------------------
+// fused RK4 model
+// --------------------------------------------------------------------------------------------
+struct fb_model {
+    fb_ctx *c;
+    float nu, dt;
+    cf *ZA, *ZB, *ACC, *TT, *W4;    // private layouts, nx*P complex each (W4: 4 of them)
+    float *src;                      // vort_src or NULL (== zeros)
+    cf *nat[3];                      // natural-layout temporaries for the record path (lazy)
+    bool primed;                     // W4 holds the block-backward derivatives of ZA
+};
+
+extern "C" int fb_model_create(fb_model **out, fb_ctx *c, float nu, float dt)
+{
+    if (!out || !c) return fail(FB_EINVAL, "fb_model_create: NULL");
+    *out = nullptr;
+    fb_model *m = new fb_model();
+    memset(m, 0, sizeof(*m));
+    m->c = c; m->nu = nu; m->dt = dt;
+    const size_t n = priv_elems(c) * sizeof(cf);
+    cf **arr[] = {&m->ZA, &m->ZB, &m->ACC, &m->TT};
+    for (auto p : arr) {
+        if (hipMalloc((void **)p, n) != hipSuccess) { fb_model_destroy(m); return fail(FB_ENOMEM, "model allocation failed"); }
+        hipMemsetAsync(*p, 0, n, c->stream);
+    }
+    if (hipMalloc((void **)&m->W4, 4 * n) != hipSuccess) { fb_model_destroy(m); return fail(FB_ENOMEM, "model allocation failed"); }
+    hipMemsetAsync(m->W4, 0, 4 * n, c->stream);
+    *out = m;
+    return FB_OK;
+}
+
+extern "C" int fb_model_destroy(fb_model *m)
+{
+    if (!m) return FB_OK;
+    hipFree(m->ZA); hipFree(m->ZB); hipFree(m->ACC); hipFree(m->TT); hipFree(m->W4);
+    if (m->src) hipFree(m->src);
+    for (auto p : m->nat) if (p) hipFree(p);
+    delete m;
+    return FB_OK;
+}
+
+extern "C" int fb_model_info(fb_model *m, size_t *hbm, size_t *alg)
+{
+    if (!m) return fail(FB_EINVAL, "model NULL");
+    const fb_ctx *c = m->c;
+    if (hbm) *hbm = 8 * priv_elems(c) * sizeof(cf) + (m->src ? (size_t)c->nx * c->ny * 4 : 0);
+    if (alg) *alg = (size_t)320 * c->nx * c->ny;
+    return FB_OK;
+}
+
+extern "C" int fb_model_set_vort(fb_model *m, const float *d_vort)
+{
+    if (!m || !d_vort) return fail(FB_EINVAL, "fb_model_set_vort: NULL");
+    fb_ctx *c = m->c;
+    HIPCHK(hipMemsetAsync(m->ZA, 0, priv_elems(c) * sizeof(cf), c->stream));
+    m->primed = false;
+    return r2c_private(c, d_vort, m->ZA);                   // main.cpp:256
+}
+
+extern "C" int fb_model_set_source(fb_model *m, const float *d_src)
+{
+    if (!m) return fail(FB_EINVAL, "model NULL");
+    fb_ctx *c = m->c;
+    const size_t n = (size_t)c->nx * c->ny * sizeof(float);
+    if (!d_src) { if (m->src) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(m->src); m->src = nullptr; } return FB_OK; }
+    if (!m->src && hipMalloc((void **)&m->src, n) != hipSuccess) return fail(FB_ENOMEM, "source allocation failed");
+    HIPCHK(hipMemcpyAsync(m->src, d_src, n, hipMemcpyDeviceToDevice, c->stream));
+    return FB_OK;
+}
+
+static MidArgs mid_args(fb_model *m, int stage)
+{
+    fb_ctx *c = m->c;
+    MidArgs a;
+    a.Tin = m->TT; a.Zbase = m->ZA; a.Zcur = m->ZB; a.Acc = m->ACC; a.Zout = m->ZA; a.W4 = m->W4;
+    a.fstride = (long)priv_elems(c); a.P = c->P; a.N1 = c->N1; a.N2 = c->N2; a.ky0 = 0; a.stage = stage;
+    a.nu = m->nu; a.dt = m->dt; a.coef = make_coef(c); a.tw_n = c->d_tw_n2; a.tw_big = c->d_tw_big;
+    return a;
+}
+
+extern "C" int fb_model_step(fb_model *m, int nsteps)
+{
+    if (!m || nsteps < 0) return fail(FB_EINVAL, "fb_model_step: bad argument");
+    fb_ctx *c = m->c;
+    int rc;
+    if (nsteps == 0) return FB_OK;
+    if (!m->primed) {
+        if ((rc = launch_col_mid(c, mid_args(m, -1)))) return rc;
+        m->primed = true;
+    }
+    const float scale = 1.0f / (float)((size_t)c->nx * c->ny);
+    for (int s = 0; s < nsteps; ++s) {
+        for (int k = 0; k < 4; ++k) {
+            if ((rc = launch_col_strided<+1>(c, m->W4, 4, (long)priv_elems(c)))) return rc;
+            RowArgs a = row_args_base(c);
+            a.M = m->W4; a.m_fstride = (long)priv_elems(c); a.T = m->TT; a.src = m->src; a.scale = scale;
+            if ((rc = launch_row<ROW_FUSED>(c, a))) return rc;
+            if ((rc = launch_col_strided<-1>(c, m->TT, 1, 0))) return rc;
+            if ((rc = launch_col_mid(c, mid_args(m, k)))) return rc;
+        }
+    }
+    return FB_OK;
+}
+
+extern "C" int fb_model_time_steps(fb_model *m, int nsteps, float *total_ms)
+{
+    if (!m || !total_ms) return fail(FB_EINVAL, "fb_model_time_steps: NULL");
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, m->c->stream));
+    int rc = fb_model_step(m, nsteps);
+    HIPCHK(hipEventRecord(e1, m->c->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(total_ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return rc;
+}
+
+extern "C" int fb_model_get_spectrum(fb_model *m, float *d_spec)
+{
+    if (!m || !d_spec) return fail(FB_EINVAL, "fb_model_get_spectrum: NULL");
+    return relayout(m->c, m->ZA, (cf *)d_spec, false);
+}
+
+extern "C" int fb_model_set_spectrum(fb_model *m, const float *d_spec)
+{
+    if (!m || !d_spec) return fail(FB_EINVAL, "fb_model_set_spectrum: NULL");
+    m->primed = false;
+    return relayout(m->c, (const cf *)d_spec, m->ZA, true);
+}
+
+extern "C" int fb_model_get_vort(fb_model *m, float *d_vort)
+{
+    if (!m || !d_vort) return fail(FB_EINVAL, "fb_model_get_vort: NULL");
+    fb_ctx *c = m->c;
+    int rc;
+    if ((rc = ensure_scratch(c))) return rc;
+    // copy of vort_c (main.cpp:273), c2r, normalise (main.cpp:275)
+    HIPCHK(hipMemcpyAsync(c->d_scratch, m->ZA, priv_elems(c) * sizeof(cf), hipMemcpyDeviceToDevice, c->stream));
+    return c2r_private(c, c->d_scratch, d_vort, 1.0f / (float)((size_t)c->nx * c->ny));
+}
+
+extern "C" int fb_model_get_diag(fb_model *m, float *d_psi, float *d_u, float *d_v)
+{
+    if (!m) return fail(FB_EINVAL, "model NULL");
+    fb_ctx *c = m->c;
+    const size_t n = (size_t)c->nx * c->hy * sizeof(cf);
+    for (auto &p : m->nat)
+        if (!p && hipMalloc((void **)&p, n) != hipSuccess) return fail(FB_ENOMEM, "record-path allocation failed");
+    int rc;
+    float *vc = (float *)m->nat[0], *psi = (float *)m->nat[1], *tmp = (float *)m->nat[2];
+    if ((rc = fb_model_get_spectrum(m, vc))) return rc;
+    if ((rc = fb_invert_laplacian(c, vc, psi))) return rc;                       // main.cpp:179
+    if (d_psi && (rc = fb_c2r(c, psi, d_psi, 1))) return rc;                     // :185-188
+    if (d_u) {
+        if ((rc = fb_grady(c, psi, tmp)) || (rc = fb_c2r(c, tmp, d_u, 1)) || (rc = fb_negate(c, d_u))) return rc;   // :198-201
+    }
+    if (d_v) {
+        if ((rc = fb_gradx(c, psi, tmp)) || (rc = fb_c2r(c, tmp, d_v, 1))) return rc;                                 // :212-214
+    }
+    return FB_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// field I/O (host): fieldio.cpp:7-33 -- same bytes on disk, same stderr lines, plus a status
+// --------------------------------------------------------------------------------------------
+extern "C" int fb_write_field(const char *filename, const float *data, size_t len)
+{
+    if (!filename || !data) return fail(FB_EINVAL, "fb_write_field: NULL");
+    FILE *f = fopen(filename, "wb");
+    if (!f) { perror("Write field."); return fail(FB_EIO, std::string("cannot open ") + filename); }
+    const size_t n = fwrite(data, sizeof(float), len, f);
+    fclose(f);
+    fprintf(stderr, "Output %s\n", filename);                 // fieldio.cpp:18
+    return n == len ? FB_OK : fail(FB_EIO, std::string("short write: ") + filename);
+}
+
+extern "C" int fb_read_field(const char *filename, float *data, size_t len)
+{
+    if (!filename || !data) return fail(FB_EINVAL, "fb_read_field: NULL");
+    FILE *f = fopen(filename, "rb");
+    if (!f) { perror("Read field."); return fail(FB_EIO, std::string("cannot open ") + filename); }
+    const size_t n = fread(data, sizeof(float), len, f);
+    fclose(f);
+    fprintf(stderr, "%d bytes read: %s\n", (int)n, filename);  // fieldio.cpp:32 (elements, labelled bytes)
+    return n == len ? FB_OK : fail(FB_EIO, std::string("short read: ") + filename);
+}
