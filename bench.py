@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""bench.py -- RK4 steps/s of the pseudospectral barotropic-vorticity hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One "step" = one RK4 step (4 stages = 16 c2r + 4 r2c 2-D FFTs + all pointwise work of
+main.cpp:286-317) of the synthetic workload below, state resident in HBM.  Prints ONE JSON line.
+
+Workload at N=1: BASELINE.json configs[2] -- 4096x4096 Kuo2004 initial field, fp32,
+dt = 3*1024/4096 s (the reference's dt=3 s is unstable above N~2300).
+For N>1 the same grid is split into x-row / ky-column slabs (strong scaling), see DESIGN.md.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+# algorithmic bytes per launch, in units of N^2 bytes (every 1-D pass over a field
+# reads + writes one N^2 float-equivalent array = 8 N^2 B; the x pass is two sub-pass kernels, each
+# credited half).  Sum over the four kernels of a stage = 80 N^2; x 4 stages = 320 N^2 per step.
+ALG_N2 = {"k_col_strided_bwd4": 16.0, "k_row_fused": 40.0, "k_col_strided_fwd1": 4.0, "k_col_mid": 20.0}
+
+
+def cpu_baseline(n, dt, kind, steps):
+    """Oracle ("port") timed on ONE host core -- the reference is single-threaded."""
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
+    except OSError:
+        pass
+    m = O.Model(n, n, dt=dt)
+    m.set_vort(O.make_field(kind, n))
+    m.step(1)
+    t0 = time.perf_counter()
+    m.step(steps)
+    el = time.perf_counter() - t0
+    return {"value": steps / el, "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": "%dx%d %s, %d RK4 steps after 1 warm-up, oracle/liboracle.so (own FFT, reference loop structure), 1 thread"
+                      % (n, n, kind, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=4096, help="grid points per side")
+    ap.add_argument("--kind", default=None, help="initial field (default: kuo2004 for n>=4096 else elliptic)")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+
+    import xlab_fftbarotropic_amd as X
+    n = args.n
+    kind = args.kind or ("kuo2004" if n >= 4096 else "elliptic")
+    dt = 3.0 if n <= 1024 else 3.0 * 1024 / n
+    K, W = args.steps, args.warmup
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from importlib import import_module
+        slab = import_module("xlab-fftbarotropic_amd.slab")
+        model = slab.SlabModel(n, n, dt=dt, rank=rank, world=world)
+        model.set_vort_local(slab.local_rows(X.make_field(kind, n), rank, world))
+        barrier = dist.barrier
+    else:
+        model = X.Model(n, n, dt=dt)
+        model.set_vort(X.make_field(kind, n))
+
+        def barrier():
+            return None
+
+    model.step(W)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.step(K)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = 1e3 * elapsed / K
+    steps_per_s = K / elapsed
+    alg_bytes = 320.0 * n * n
+    out = {
+        "metric": "RK4 steps/sec, %dx%d periodic grid" % (n, n), "value": steps_per_s, "unit": "steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%dx%d %s initial field, nu=6.5, L=600 km, dt=%.4g s, 4 RK stages/step, fused HIP path"
+                               % (n, n, kind, dt), "grid": [n, n], "parallelism": "slab%d" % world if world > 1 else "single"},
+        "achieved_hbm_GBs": alg_bytes * steps_per_s / 1e9,
+        "step_roofline_frac": alg_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBS * world),
+    }
+
+    if rank == 0 and world == 1:
+        # per-kernel HIP-event timing over a second pass of the same K steps (events on the launch stream)
+        prof = model.profile_steps(K)
+        torch.cuda.synchronize()
+        per = {k: (ms / max(cnt, 1)) for k, (ms, cnt) in prof.items()}
+        tot = {k: ms for k, (ms, cnt) in prof.items()}
+        dom = max(tot, key=tot.get)
+        ach = ALG_N2[dom] * n * n / (per[dom] * 1e-3) / 1e9
+        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "avg_launch_ms": per[dom], "alg_bytes_per_launch": ALG_N2[dom] * n * n}
+        out["kernels_ms_per_launch"] = per
+        out["kernels_ms_per_step"] = {k: v / K for k, v in tot.items()}
+        if args.cpu_steps > 0:
+            out["cpu_baseline"] = cpu_baseline(n, dt, kind, args.cpu_steps)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -126,9 +126,14 @@ int fb_model_get_spectrum(fb_model *m, float *d_spec);
 int fb_model_set_spectrum(fb_model *m, const float *d_spec);
 /* bytes of HBM the model holds, and the algorithmic bytes of one step (320*nx*ny) */
 int fb_model_info(fb_model *m, size_t *hbm_bytes, size_t *alg_bytes_per_step);
-/* times `nsteps` steps with HIP events on the model's stream; returns ms total and, if
- * kernel_ms != NULL, the summed duration of the dominant kernel class (column-mid) */
+/* times `nsteps` steps with HIP events on the model's stream;
+ * total_ms = wall time of the whole batch of steps on the device */
 int fb_model_time_steps(fb_model *m, int nsteps, float *total_ms);
+/* the same steps with a HIP-event pair around every kernel launch (on the model's stream).
+ * Kernel classes: 0 = k_col_strided<+1> (4 fields, backward x sub-pass), 1 = k_row<FUSED>,
+ * 2 = k_col_strided<-1> (tendency, forward x sub-pass), 3 = k_col_mid.  ms_sum[4] receives the
+ * summed durations, launches[4] the launch counts. */
+int fb_model_profile_steps(fb_model *m, int nsteps, float *ms_sum, int *launches);
 
 /* ---------------------------------------------------------------------------------------
  * Field I/O on HOST buffers.  Replaces writeField / readField (fieldio.hpp:5-6,
@@ -136,6 +141,17 @@ int fb_model_time_steps(fb_model *m, int nsteps, float *total_ms);
  * ------------------------------------------------------------------------------------- */
 int fb_write_field(const char *filename, const float *h_data, size_t len);
 int fb_read_field(const char *filename, float *h_data, size_t len);
+
+/* ---------------------------------------------------------------------------------------
+ * Initial-field synthesis on HOST buffers (nx*ny float32), the inputs of the benchmark configs.
+ * kind = "elliptic"  makefield-elliptic-vortex.cpp:14-52
+ *        "kuo2004"   makefield-Kuo2004.cpp:30-41 + field_generator.cpp:10-28 (buffer zeroed first)
+ *        "gaussian"  makefield-gaussian.cpp:14-31
+ *        "const"     makefield-const-vortex.cpp:14-38
+ * fb_make_source_kuo2004: the FIFO producer's source cake, vort_src_input.cpp:35-46.
+ * ------------------------------------------------------------------------------------- */
+int fb_make_field(const char *kind, int nx, int ny, float lx, float ly, float *h_vort);
+int fb_make_source_kuo2004(int nx, int ny, float lx, float ly, float duration, float *h_src);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime: it must be in the process before libfftbaro.so is
+    # dlopen'ed, so that both resolve to ONE libamdhip64 (two runtimes cannot share a device).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = _build.LIB
     if _build.stale():
         try:
@@ -70,6 +76,9 @@ def lib():
     L.fb_model_set_spectrum.argtypes = [vp, fp]
     L.fb_model_info.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.fb_model_time_steps.argtypes = [vp, ip, C.POINTER(C.c_float)]
+    L.fb_model_profile_steps.argtypes = [vp, ip, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.fb_make_field.argtypes = [C.c_char_p, ip, ip, C.c_float, C.c_float, C.c_void_p]
+    L.fb_make_source_kuo2004.argtypes = [ip, ip, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.fb_write_field.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
     L.fb_read_field.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
     _lib = L
@@ -83,7 +92,7 @@ EXPORTS = [
     "fb_backward_normalize", "fb_negate", "fb_jacobian", "fb_spec_axpy", "fb_spec_evolve", "fb_spec_rk4_combine",
     "fb_model_create", "fb_model_destroy", "fb_model_set_vort", "fb_model_set_source", "fb_model_step",
     "fb_model_get_vort", "fb_model_get_diag", "fb_model_get_spectrum", "fb_model_set_spectrum", "fb_model_info",
-    "fb_model_time_steps", "fb_write_field", "fb_read_field",
+    "fb_model_time_steps", "fb_model_profile_steps", "fb_write_field", "fb_read_field", "fb_make_field", "fb_make_source_kuo2004",
 ]
 
 
@@ -258,6 +267,14 @@ class Model:
         check(lib().fb_model_time_steps(self._h, n, C.byref(ms)))
         return ms.value
 
+    KERNEL_CLASSES = ("k_col_strided_bwd4", "k_row_fused", "k_col_strided_fwd1", "k_col_mid")
+
+    def profile_steps(self, n):
+        """HIP-event time per kernel class over n steps: {class: (total_ms, launches)}."""
+        ms = (C.c_float * 4)(); cnt = (C.c_int * 4)()
+        check(lib().fb_model_profile_steps(self._h, n, ms, cnt))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
+
     def vort(self):
         out = self.fop.empty_real(); check(lib().fb_model_get_vort(self._h, _ptr(out))); return out
 
@@ -285,4 +302,19 @@ def write_field(path, data):
 def read_field(path, n):
     out = np.empty(n, dtype=np.float32)
     check(lib().fb_read_field(path.encode(), out.ctypes.data, n))
+    return out
+
+
+def make_field(kind, nx, ny=None, Lx=600000.0, Ly=600000.0):
+    """Host-side initial vorticity (makefield-*.cpp restated with run-time grid size)."""
+    ny = ny or nx
+    out = np.empty((nx, ny), dtype=np.float32)
+    check(lib().fb_make_field(kind.encode(), nx, ny, Lx, Ly, out.ctypes.data))
+    return out
+
+
+def make_source_kuo2004(nx, ny=None, Lx=600000.0, Ly=600000.0, duration=10800.0):
+    ny = ny or nx
+    out = np.empty((nx, ny), dtype=np.float32)
+    check(lib().fb_make_source_kuo2004(nx, ny, Lx, Ly, duration, out.ctypes.data))
     return out

@@ -4,7 +4,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "fftbaro.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "fb_kernels.h"), os.path.join(HERE, "csrc", "fb_fft_core.h"),
+SRC_HOST = [os.path.join(HERE, "csrc", "fb_fields.cpp")]
+DEPS = [SRC] + SRC_HOST + [ os.path.join(HERE, "csrc", "fb_kernels.h"), os.path.join(HERE, "csrc", "fb_fft_core.h"),
         os.path.join(os.path.dirname(HERE), "include", "fftbaro.h")]
 LIB = os.path.join(HERE, "lib", "libfftbaro.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -23,7 +24,7 @@ def build_lib(force=False, verbose=False):
     if not (force or stale()):
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-o", LIB, SRC]
+    cmd = [HIPCC] + FLAGS + ["-o", LIB, SRC] + SRC_HOST
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

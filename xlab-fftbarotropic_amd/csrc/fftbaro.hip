@@ -564,7 +564,18 @@ static MidArgs mid_args(fb_model *m, int stage)
     return a;
 }
 
-extern "C" int fb_model_step(fb_model *m, int nsteps)
+// optional per-launch HIP-event profiler (bench.py's roofline leg)
+struct StepProf {
+    std::vector<hipEvent_t> ev0[4], ev1[4];
+    hipStream_t stream;
+    int begin(int cls) { hipEvent_t a, b; if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 1;
+                         ev0[cls].push_back(a); ev1[cls].push_back(b); return hipEventRecord(a, stream) != hipSuccess; }
+    int end(int cls) { return hipEventRecord(ev1[cls].back(), stream) != hipSuccess; }
+};
+#define PROF_BEGIN(cls) do { if (prof && prof->begin(cls)) return fail(FB_EHIP, "event record failed"); } while (0)
+#define PROF_END(cls) do { if (prof && prof->end(cls)) return fail(FB_EHIP, "event record failed"); } while (0)
+
+static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
 {
     if (!m || nsteps < 0) return fail(FB_EINVAL, "fb_model_step: bad argument");
     fb_ctx *c = m->c;
@@ -577,16 +588,26 @@ extern "C" int fb_model_step(fb_model *m, int nsteps)
     const float scale = 1.0f / (float)((size_t)c->nx * c->ny);
     for (int s = 0; s < nsteps; ++s) {
         for (int k = 0; k < 4; ++k) {
+            PROF_BEGIN(0);
             if ((rc = launch_col_strided<+1>(c, m->W4, 4, (long)priv_elems(c)))) return rc;
+            PROF_END(0);
             RowArgs a = row_args_base(c);
             a.M = m->W4; a.m_fstride = (long)priv_elems(c); a.T = m->TT; a.src = m->src; a.scale = scale;
+            PROF_BEGIN(1);
             if ((rc = launch_row<ROW_FUSED>(c, a))) return rc;
+            PROF_END(1);
+            PROF_BEGIN(2);
             if ((rc = launch_col_strided<-1>(c, m->TT, 1, 0))) return rc;
+            PROF_END(2);
+            PROF_BEGIN(3);
             if ((rc = launch_col_mid(c, mid_args(m, k)))) return rc;
+            PROF_END(3);
         }
     }
     return FB_OK;
 }
+
+extern "C" int fb_model_step(fb_model *m, int nsteps) { return model_step_impl(m, nsteps, nullptr); }
 
 extern "C" int fb_model_time_steps(fb_model *m, int nsteps, float *total_ms)
 {
@@ -599,6 +620,25 @@ extern "C" int fb_model_time_steps(fb_model *m, int nsteps, float *total_ms)
     HIPCHK(hipEventSynchronize(e1));
     HIPCHK(hipEventElapsedTime(total_ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
+    return rc;
+}
+
+extern "C" int fb_model_profile_steps(fb_model *m, int nsteps, float *ms_sum, int *launches)
+{
+    if (!m || !ms_sum || !launches) return fail(FB_EINVAL, "fb_model_profile_steps: NULL");
+    StepProf prof; prof.stream = m->c->stream;
+    if (!m->primed) { int rc0 = model_step_impl(m, 0, nullptr); (void)rc0; }
+    int rc = model_step_impl(m, nsteps, &prof);
+    HIPCHK(hipStreamSynchronize(m->c->stream));
+    for (int cls = 0; cls < 4; ++cls) {
+        ms_sum[cls] = 0.f; launches[cls] = (int)prof.ev0[cls].size();
+        for (size_t i = 0; i < prof.ev0[cls].size(); ++i) {
+            float ms = 0.f;
+            if (i < prof.ev1[cls].size() && hipEventElapsedTime(&ms, prof.ev0[cls][i], prof.ev1[cls][i]) == hipSuccess) ms_sum[cls] += ms;
+            hipEventDestroy(prof.ev0[cls][i]);
+            if (i < prof.ev1[cls].size()) hipEventDestroy(prof.ev1[cls][i]);
+        }
+    }
     return rc;
 }
 
