@@ -201,51 +201,32 @@ FB_DEV void wave_fft_B2A(const cf *in /*[NLB]*/, float4 *out /*[n/8]*/, cf *lds,
 // radix R when fed from registers):  reg[m*R + q]  <->  position (t + m*T) + q*N/R.
 // ============================================================================================
 FB_DEV int lds_pad(int e) { return e + (e >> 4); }
+// Opaque copy of a per-thread index: address arithmetic derived from it cannot be hoisted out
+// of the enclosing loop (LICM would otherwise keep dozens of invariant addresses live in VGPRs).
+FB_DEV int launder(int v) { asm volatile("" : "+v"(v)); return v; }
 
-// One Stockham stage.  tw: stage table laid out [(m*(R-1) + (q-1))*T + t] (forward values).
-template <int N, int R, int NS, int DIR, bool FROM_REGS, bool TO_REGS>
-FB_DEV void stockham_stage(cf *lds, int t, const cf *__restrict__ tw, cf *reg /*[16]*/)
-{
-    constexpr int T = N / 16, NB = 16 / R, STR = N / R;
-#pragma unroll
-    for (int m = 0; m < NB; ++m) {
-        const int j = t + m * T;
-        cf *v = reg + m * R;
-        if (!FROM_REGS) {
-#pragma unroll
-            for (int q = 0; q < R; ++q) v[q] = lds[lds_pad(j + q * STR)];
-        }
-        if (NS > 1) {
-#pragma unroll
-            for (int q = 1; q < R; ++q) v[q] = cmul_dir<DIR>(v[q], tw[(m * (R - 1) + (q - 1)) * T + t]);
-        }
-        Bfly<R, DIR>::run(v);
-    }
-    if (!TO_REGS) {
-        if (!FROM_REGS) __syncthreads();          // everyone has finished reading this buffer
-#pragma unroll
-        for (int m = 0; m < NB; ++m) {
-            const int j = t + m * T;
-            const int j0 = (j / NS) * NS * R + (j % NS);
-#pragma unroll
-            for (int q = 0; q < R; ++q) lds[lds_pad(j0 + q * NS)] = reg[m * R + q];
-        }
-        __syncthreads();
-    }
-}
+// Workgroup barrier that orders LDS traffic only: waits lgkmcnt(0), not vmcnt, so LDS-DMA
+// prefetches and global stores stay in flight across it (cdna_hip_programming.md, section 5).
+FB_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Row plans: radices of the BACKWARD (c2r) row transform; the forward transform uses them
+// Row plans: radices of the BACKWARD (c2r) row transform; the forward transform walks them
 // reversed, so that the backward pass's final register distribution feeds the forward pass.
+// Plans up to 4096 are palindromes: one stage-twiddle table (kept in registers) serves both
+// directions.  Larger rows stream their twiddles from the (L2-resident) table instead.
 template <int N> struct RowPlan;
-template <> struct RowPlan<64>    { static constexpr int S = 2; static constexpr int R[4] = {4, 16, 1, 1}; };
-template <> struct RowPlan<128>   { static constexpr int S = 2; static constexpr int R[4] = {8, 16, 1, 1}; };
+template <> struct RowPlan<64>    { static constexpr int S = 2; static constexpr int R[4] = {8, 8, 1, 1}; };
+template <> struct RowPlan<128>   { static constexpr int S = 3; static constexpr int R[4] = {4, 8, 4, 1}; };
 template <> struct RowPlan<256>   { static constexpr int S = 2; static constexpr int R[4] = {16, 16, 1, 1}; };
-template <> struct RowPlan<512>   { static constexpr int S = 3; static constexpr int R[4] = {4, 8, 16, 1}; };
-template <> struct RowPlan<1024>  { static constexpr int S = 3; static constexpr int R[4] = {8, 8, 16, 1}; };
-template <> struct RowPlan<2048>  { static constexpr int S = 3; static constexpr int R[4] = {8, 16, 16, 1}; };
+template <> struct RowPlan<512>   { static constexpr int S = 3; static constexpr int R[4] = {8, 8, 8, 1}; };
+template <> struct RowPlan<1024>  { static constexpr int S = 3; static constexpr int R[4] = {8, 16, 8, 1}; };
+template <> struct RowPlan<2048>  { static constexpr int S = 3; static constexpr int R[4] = {16, 8, 16, 1}; };
 template <> struct RowPlan<4096>  { static constexpr int S = 3; static constexpr int R[4] = {16, 16, 16, 1}; };
 template <> struct RowPlan<8192>  { static constexpr int S = 4; static constexpr int R[4] = {4, 8, 16, 16}; };
-template <> struct RowPlan<16384> { static constexpr int S = 4; static constexpr int R[4] = {8, 8, 16, 16}; };
+template <> struct RowPlan<16384> { static constexpr int S = 4; static constexpr int R[4] = {8, 16, 16, 8}; };
+template <int N> struct RowRes { static constexpr bool value = N <= 4096; };   // twiddles register-resident
+
+// register order of a radix-R stage: reg[e], e = m*R + q  <->  position t + ord_i<R>(e) * (N/16)
+template <int R> constexpr int ord_i(int e) { return (e / R) + (16 / R) * (e % R); }
 
 // Twiddle table offsets (in complex elements) per stage for a plan walked in the given order.
 // Stage s (s >= 1) stores (16/R)*(R-1)*T entries; stage 0 has NS = 1 and stores nothing.
@@ -258,33 +239,122 @@ template <int N, bool FWD> struct RowTw {
     static constexpr int total() { return offset(RowPlan<N>::S); }
 };
 
-// Whole backward FFT: input in LDS (natural order, padded), output in registers (D_R, R = last radix).
-template <int N>
-FB_DEV void row_fft_bwd(cf *lds, int t, const cf *__restrict__ tw, cf *reg)
+// true when the forward plan (reversed radices) equals the backward plan
+template <int N> struct RowPlanSymmetric {
+    static constexpr bool value = []() {
+        for (int s = 0; s < RowPlan<N>::S; ++s) if (RowTw<N, true>::radix(s) != RowTw<N, false>::radix(s)) return false;
+        return true; }();
+};
+
+// Twiddle source of one direction.  Table layout (host, make_row_table): offset(s) + e*T + t for
+// entry e = m*(R-1) + (q-1) of stage s; the value depends on (j % NS, q) only, j = t + m*T.
+//   RES : the LAST stage's values (unique per thread) live in registers, loaded once per
+//         workgroup; the middle stages' few distinct values (NS*(R-1) <= 240) come from a small
+//         LDS table shared by the workgroup.  Keeps the FFT at ~160 VGPRs.
+//   !RES: everything streamed from the (L2-resident) global table.
+template <int N, bool FWD, bool RES> struct RowTwSrc;
+template <int N, bool FWD> struct RowTwSrc<N, FWD, true> {
+    using TW = RowTw<N, FWD>;
+    static constexpr int S = RowPlan<N>::S, T = N / 16;
+    static constexpr int per(int s) { return (16 / TW::radix(s)) * (TW::radix(s) - 1); }
+    // LDS table: stages 1..S-2, stage s holds ns(s)*(R_s-1) entries [k][q-1]
+    static constexpr int lsize(int s) { return (s >= 1 && s <= S - 2) ? TW::ns(s) * (TW::radix(s) - 1) : 0; }
+    static constexpr int loff(int s) { int v = 0; for (int i = 1; i < s; ++i) v += lsize(i); return v; }
+    static constexpr int LDS_CF = loff(S - 1) > 0 ? ((loff(S - 1) + 1) / 2) * 2 : 0;
+    cf w[per(S - 1)];
+    const cf *ltab; int t;
+    // cooperative: fills the LDS table (all threads of the workgroup), then the registers
+    FB_DEV void init(const cf *__restrict__ tab, cf *lds_tab, int t_, int tid, int nthreads)
+    {
+        t = t_; ltab = lds_tab;
+        if constexpr (S >= 3) fill<1>(tab, lds_tab, tid, nthreads);
+        if constexpr (S >= 4) fill<2>(tab, lds_tab, tid, nthreads);
+#pragma unroll
+        for (int e = 0; e < per(S - 1); ++e) w[e] = tab[TW::offset(S - 1) + e * T + t_];
+    }
+    template <int s> FB_DEV void fill(const cf *__restrict__ tab, cf *lds_tab, int tid, int nthreads)
+    {
+        constexpr int R = TW::radix(s), NS = TW::ns(s);
+        for (int i = tid; i < NS * (R - 1); i += nthreads) {
+            const int k = i / (R - 1), qm = i - k * (R - 1);      // j = k (m = 0, t = k < NS <= T)
+            lds_tab[loff(s) + i] = tab[TW::offset(s) + qm * T + k];
+        }
+    }
+    template <int s> FB_DEV cf get(int e) const
+    {
+        if constexpr (s == S - 1) return w[e];
+        else {
+            constexpr int R = TW::radix(s), NS = TW::ns(s);
+            const int m = e / (R - 1), qm = e - m * (R - 1);
+            return ltab[loff(s) + ((t + m * T) % NS) * (R - 1) + qm];
+        }
+    }
+};
+template <int N, bool FWD> struct RowTwSrc<N, FWD, false> {
+    using TW = RowTw<N, FWD>;
+    static constexpr int LDS_CF = 0;
+    const cf *__restrict__ tab; int t;
+    FB_DEV void init(const cf *__restrict__ tab_, cf *, int t_, int, int) { tab = tab_; t = t_; }
+    template <int s> FB_DEV cf get(int e) const { return tab[TW::offset(s) + e * TW::T + t]; }
+};
+
+// One Stockham stage (stage index SI of its plan).  LDS addresses are written as
+// (per-thread base) + (compile-time offset) wherever the padding is linear in q, so that the DS
+// instructions carry immediate offsets instead of one address register per element.
+template <int N, int R, int NS, int DIR, bool FROM_REGS, bool TO_REGS, int SI, class SRC>
+FB_DEV void stockham_stage(cf *lds, int t, const SRC &src, cf *reg /*[16]*/)
 {
-    using P = RowPlan<N>; using TW = RowTw<N, false>;
-    constexpr int S = P::S;
-    stockham_stage<N, TW::radix(0), 1, +1, false, false>(lds, t, tw, reg);
-    if constexpr (S == 2) {
-        stockham_stage<N, TW::radix(1), TW::ns(1), +1, false, true>(lds, t, tw + TW::offset(1), reg);
-    } else if constexpr (S == 3) {
-        stockham_stage<N, TW::radix(1), TW::ns(1), +1, false, false>(lds, t, tw + TW::offset(1), reg);
-        stockham_stage<N, TW::radix(2), TW::ns(2), +1, false, true>(lds, t, tw + TW::offset(2), reg);
-    } else {
-        stockham_stage<N, TW::radix(1), TW::ns(1), +1, false, false>(lds, t, tw + TW::offset(1), reg);
-        stockham_stage<N, TW::radix(2), TW::ns(2), +1, false, false>(lds, t, tw + TW::offset(2), reg);
-        stockham_stage<N, TW::radix(3), TW::ns(3), +1, false, true>(lds, t, tw + TW::offset(3), reg);
+    constexpr int T = N / 16, NB = 16 / R, STR = N / R;
+    constexpr bool RD_LIN = (STR % 16) == 0;                           // pad(j + q STR) = pad(j) + q (STR + STR/16)
+    constexpr bool WR_LIN = ((NS * R) % 16 == 0) && (NS % 16 == 0 || NS * R <= 16);
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+        const int j = t + m * T;
+        cf *v = reg + m * R;
+        if (!FROM_REGS) {
+            const cf *rb = lds + lds_pad(j);
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[q] = RD_LIN ? rb[q * (STR + STR / 16)] : lds[lds_pad(j + q * STR)];
+        }
+        if (NS > 1) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) v[q] = cmul_dir<DIR>(v[q], src.template get<SI>(m * (R - 1) + (q - 1)));
+        }
+        Bfly<R, DIR>::run(v);
+    }
+    if (!TO_REGS) {
+        lds_barrier();                            // previous readers of this buffer are done
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const int j = t + m * T;
+            const int j0 = (j / NS) * NS * R + (j % NS);
+            cf *wb = lds + lds_pad(j0);
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                if (WR_LIN) wb[q * NS + (q * NS) / 16] = reg[m * R + q];
+                else lds[lds_pad(j0 + q * NS)] = reg[m * R + q];
+            }
+        }
+        lds_barrier();
     }
 }
 
-// Whole forward FFT: input in registers (D_R, R = first radix), output in LDS (natural order, padded).
-template <int N>
-FB_DEV void row_fft_fwd(cf *lds, int t, const cf *__restrict__ tw, cf *reg)
+// Whole transform, registers -> registers.  Input order: first stage's (ord_i<R_first>), output
+// order: last stage's (ord_i<R_last>).  FWD selects direction and plan order.
+template <int N, bool FWD, class SRC>
+FB_DEV void row_fft(cf *lds, int t, const SRC &src, cf *reg)
 {
-    using P = RowPlan<N>; using TW = RowTw<N, true>;
-    constexpr int S = P::S;
-    stockham_stage<N, TW::radix(0), 1, -1, true, false>(lds, t, tw, reg);
-    stockham_stage<N, TW::radix(1), TW::ns(1), -1, false, false>(lds, t, tw + TW::offset(1), reg);
-    if constexpr (S >= 3) stockham_stage<N, TW::radix(2), TW::ns(2), -1, false, false>(lds, t, tw + TW::offset(2), reg);
-    if constexpr (S >= 4) stockham_stage<N, TW::radix(3), TW::ns(3), -1, false, false>(lds, t, tw + TW::offset(3), reg);
+    using TW = RowTw<N, FWD>;
+    constexpr int S = RowPlan<N>::S, DIR = FWD ? -1 : +1;
+    stockham_stage<N, TW::radix(0), 1, DIR, true, false, 0>(lds, launder(t), src, reg);
+    if constexpr (S == 2) {
+        stockham_stage<N, TW::radix(1), TW::ns(1), DIR, false, true, 1>(lds, launder(t), src, reg);
+    } else if constexpr (S == 3) {
+        stockham_stage<N, TW::radix(1), TW::ns(1), DIR, false, false, 1>(lds, launder(t), src, reg);
+        stockham_stage<N, TW::radix(2), TW::ns(2), DIR, false, true, 2>(lds, launder(t), src, reg);
+    } else {
+        stockham_stage<N, TW::radix(1), TW::ns(1), DIR, false, false, 1>(lds, launder(t), src, reg);
+        stockham_stage<N, TW::radix(2), TW::ns(2), DIR, false, false, 2>(lds, launder(t), src, reg);
+        stockham_stage<N, TW::radix(3), TW::ns(3), DIR, false, true, 3>(lds, launder(t), src, reg);
+    }
 }

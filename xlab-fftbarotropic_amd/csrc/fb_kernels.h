@@ -134,128 +134,225 @@ template <int N> struct RowCfg {
     static constexpr int T = N / 16;
     static constexpr int G = T >= 256 ? 1 : 256 / T;
     static constexpr int THREADS = T * G;
-    static constexpr int LSTR = N + N / 16;               // padded complex per group
-    static constexpr size_t LDS_BYTES = (size_t)G * LSTR * sizeof(cf);
+    static constexpr int LSTR = N + N / 16;               // padded complex per group (exchange buffer)
+    // LDS-DMA prefetch of the next phase's two half-spectrum rows (fused mode): groups must be
+    // whole waves and buffer + staging must leave room for two workgroups per CU
+    static constexpr bool DMA = N >= 1024 && N <= 4096;
+    static constexpr int GSTR = LSTR + (DMA ? N : 0);     // complex per group incl. staging [A: N/2][B: N/2]
+    static constexpr bool RES = RowRes<N>::value;
+    static constexpr bool SHARE = RES && RowPlanSymmetric<N>::value;        // one twiddle set for both directions
+    static constexpr int TWL_B = RowTwSrc<N, false, RES>::LDS_CF, TWL_F = SHARE ? 0 : RowTwSrc<N, true, RES>::LDS_CF;
+    static constexpr size_t LDS_BYTES = ((size_t)G * GSTR + TWL_B + TWL_F) * sizeof(cf);
+    static constexpr int MIN_WAVES = THREADS == 256 ? 2 : (THREADS == 512 ? 2 : 4);
 };
 
+// element (row, k) of a mixed-space array; SLAB: the row is cut into ky slabs of ks columns that
+// live sstride apart (send/receive buffers of the multi-GPU transpose), else one pitch-ks array
+template <bool SLAB>
 FB_DEV const cf *row_ptr(const cf *base, int ks, long sstride, int row, int k)
 {
-    if (sstride == 0) return base + (size_t)row * ks + k;
+    if (!SLAB) return base + (size_t)row * ks + k;
     const int slab = k / ks;
     return base + (size_t)slab * sstride + (size_t)row * ks + (k - slab * ks);
 }
 
-// Hermitian-extend two half-spectrum rows A,B into Z = A_ext + i B_ext in LDS (SURVEY note N2:
-// imaginary parts at k=0 and k=N/2 are ignored).
-template <int N>
-FB_DEV void row_load_pair(cf *lds, int t, const cf *baseA, const cf *baseB, int rowA, int rowB, int ks, long sstride)
+// Hermitian-extend two half-spectrum rows A,B into Z = A_ext + i B_ext, straight into the first
+// backward stage's registers (SURVEY note N2: imaginary parts at k=0 and k=N/2 are ignored).
+// Thread t owns positions t + i*T: for i < 8 that is k itself, for i >= 8 the mirror of N - pos.
+template <int N, bool SLAB>
+FB_DEV void row_load_pair(cf *reg, int t, const cf *baseA, const cf *baseB, int rowA, int rowB, int ks, long sstride)
 {
-    constexpr int T = N / 16;
+    constexpr int T = N / 16, R0 = RowTw<N, false>::radix(0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = 2 * (t + T * i);
-        const float4 a = *reinterpret_cast<const float4 *>(row_ptr(baseA, ks, sstride, rowA, k));
-        const float4 b = *reinterpret_cast<const float4 *>(row_ptr(baseB, ks, sstride, rowB, k));
-        cf z0 = cf_make(a.x - b.y, a.y + b.x), z1 = cf_make(a.z - b.w, a.w + b.z);
-        cf m0 = cf_make(a.x + b.y, b.x - a.y), m1 = cf_make(a.z + b.w, b.z - a.w);
-        if (k == 0) z0 = cf_make(a.x, b.x);
-        lds[lds_pad(k)] = z0;
-        lds[lds_pad(k + 1)] = z1;
-        if (k != 0) lds[lds_pad(N - k)] = m0;
-        lds[lds_pad(N - k - 1)] = m1;
-    }
-    if (t == 0) {
-        const cf a = *row_ptr(baseA, ks, sstride, rowA, N / 2), b = *row_ptr(baseB, ks, sstride, rowB, N / 2);
-        lds[lds_pad(N / 2)] = cf_make(a.x, b.x);
+    for (int e = 0; e < 16; ++e) {
+        const int i = ord_i<R0>(e);
+        if (i < 8) {
+            const int k = t + i * T;
+            const cf a = *row_ptr<SLAB>(baseA, ks, sstride, rowA, k), b = *row_ptr<SLAB>(baseB, ks, sstride, rowB, k);
+            reg[e] = (i == 0 && t == 0) ? cf_make(a.x, b.x) : cf_make(a.x - b.y, a.y + b.x);
+        } else {
+            const int k = (16 - i) * T - t;                 // in (0, N/2]; == N/2 only for t == 0, i == 8
+            const cf a = *row_ptr<SLAB>(baseA, ks, sstride, rowA, k), b = *row_ptr<SLAB>(baseB, ks, sstride, rowB, k);
+            reg[e] = (i == 8 && t == 0) ? cf_make(a.x, b.x) : cf_make(a.x + b.y, b.x - a.y);
+        }
     }
 }
 
-// untangle Z = FFT(t0 + i t1) in LDS into the two half spectra and store rows rowA,rowB of T
-template <int N>
-FB_DEV void row_store_pair(const cf *lds, int t, cf *T, int rowA, int rowB, int ks, long sstride)
+// untangle Z = FFT(t0 + i t1), held in the last forward stage's register order, into the two
+// half spectra and store rows rowA,rowB of T.  Only the upper half (positions >= N/2) goes
+// through LDS: the mirror of k = t + i*T (i < 8) is position (16-i)*T - t.
+template <int N, bool SLAB>
+FB_DEV void row_store_pair(cf *lds, int t, const cf *reg, bool valid, cf *T_, int rowA, int rowB, int ks, long sstride)
 {
-    constexpr int TT = N / 16;
+    constexpr int T = N / 16, RL = RowTw<N, true>::radix(RowPlan<N>::S - 1);
+    lds_barrier();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = 2 * (t + TT * i);
-        const cf zk0 = lds[lds_pad(k)], zk1 = lds[lds_pad(k + 1)];
-        const cf zn0 = lds[lds_pad((N - k) & (N - 1))], zn1 = lds[lds_pad(N - k - 1)];
-        float4 A = make_float4(0.5f * (zk0.x + zn0.x), 0.5f * (zk0.y - zn0.y), 0.5f * (zk1.x + zn1.x), 0.5f * (zk1.y - zn1.y));
-        float4 B = make_float4(0.5f * (zk0.y + zn0.y), 0.5f * (zn0.x - zk0.x), 0.5f * (zk1.y + zn1.y), 0.5f * (zn1.x - zk1.x));
-        *reinterpret_cast<float4 *>(const_cast<cf *>(row_ptr(T, ks, sstride, rowA, k))) = A;
-        *reinterpret_cast<float4 *>(const_cast<cf *>(row_ptr(T, ks, sstride, rowB, k))) = B;
+    for (int e = 0; e < 16; ++e) {
+        const int i = ord_i<RL>(e);
+        if (i >= 8) lds[lds_pad(t + i * T)] = reg[e];
     }
-    if (t == 0) {
-        const cf z = lds[lds_pad(N / 2)];
-        *const_cast<cf *>(row_ptr(T, ks, sstride, rowA, N / 2)) = cf_make(z.x, 0.f);
-        *const_cast<cf *>(row_ptr(T, ks, sstride, rowB, N / 2)) = cf_make(z.y, 0.f);
+    lds_barrier();
+    if (!valid) return;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = ord_i<RL>(e);
+        if (i < 8) {
+            const int k = t + i * T;
+            const cf zk = reg[e];
+            const cf zn = (i == 0 && t == 0) ? zk : lds[lds_pad(N - k)];
+            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, k)) = cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, k)) = cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
+        } else if (i == 8 && t == 0) {                       // Nyquist: its own mirror
+            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, N / 2)) = cf_make(reg[e].x, 0.f);
+            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, N / 2)) = cf_make(reg[e].y, 0.f);
+        }
     }
 }
 
-template <int N, int MODE>
-__global__ void __launch_bounds__(RowCfg<N>::THREADS) k_row(RowArgs a)
+// ---- LDS-DMA prefetch of two half-spectrum rows into the group's staging area ----------------
+// stg[0..N/2) = row A (k = 0..N/2-1), stg[N/2..N) = row B; the Nyquist elements travel in registers.
+template <int N, bool SLAB>
+FB_DEV void row_dma_issue(cf *stg, int t, const cf *baseA, const cf *baseB, int rowA, int rowB, int ks, long sstride,
+                          cf &nyqA, cf &nyqB)
+{
+    constexpr int T = N / 16, NW = T / 64, CH = N / 256;         // waves per group, 1-KiB chunks per row
+    const int w = t >> 6, lane = t & 63;
+#pragma unroll
+    for (int c = 0; c < CH / NW; ++c) {
+        const int ch = w + c * NW, k = ch * 128 + lane * 2;
+        cf *dstA = stg + ch * 128, *dstB = stg + N / 2 + ch * 128;   // wave-uniform; the DMA adds lane*16 B
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(baseA, ks, sstride, rowA, k),
+                                         (void __attribute__((address_space(3))) *)dstA, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(baseB, ks, sstride, rowB, k),
+                                         (void __attribute__((address_space(3))) *)dstB, 16, 0, 0);
+    }
+    if (t == 0) { nyqA = *row_ptr<SLAB>(baseA, ks, sstride, rowA, N / 2); nyqB = *row_ptr<SLAB>(baseB, ks, sstride, rowB, N / 2); }
+}
+
+// Hermitian extension from the staging area into the first backward stage's registers
+template <int N>
+FB_DEV void row_ext_from_stage(cf *reg, int t, const cf *stg, cf nyqA, cf nyqB)
+{
+    constexpr int T = N / 16, R0 = RowTw<N, false>::radix(0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = ord_i<R0>(e);
+        if (i < 8) {
+            const int k = t + i * T;
+            const cf a = stg[k], b = stg[N / 2 + k];
+            reg[e] = (i == 0 && t == 0) ? cf_make(a.x, b.x) : cf_make(a.x - b.y, a.y + b.x);
+        } else {
+            int k = (16 - i) * T - t;
+            const bool nyq = (i == 8 && t == 0);
+            if (nyq) k = 0;
+            cf a = stg[k], b = stg[N / 2 + k];
+            reg[e] = nyq ? cf_make(nyqA.x, nyqB.x) : cf_make(a.x + b.y, b.x - a.y);
+        }
+    }
+}
+
+template <int N, int MODE, bool SLAB>
+__global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_row(RowArgs a)
 {
     using C = RowCfg<N>;
     constexpr int T = C::T, G = C::G;
+    constexpr int RL = RowTw<N, false>::radix(RowPlan<N>::S - 1);      // physical-space register order
+    constexpr bool DMA = C::DMA && MODE == ROW_FUSED;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf *smem = reinterpret_cast<cf *>(smem_raw);
     const int grp = threadIdx.x / T, t = threadIdx.x - grp * T;
-    cf *lds = smem + (size_t)grp * C::LSTR;
+    cf *lds = smem + (size_t)grp * C::GSTR;
+    cf *stg = lds + C::LSTR;
     const int npairs = a.nx >> 1;
     const int iters = (npairs + gridDim.x * G - 1) / (gridDim.x * G);
 
+    // stage twiddles: once per workgroup (registers + a small LDS table) for N <= 4096, streamed otherwise
+    constexpr bool SHARE = C::SHARE;
+    cf *twl = smem + (size_t)G * C::GSTR;
+    RowTwSrc<N, false, C::RES> twb;
+    twb.init(a.tw_bwd, twl, t, threadIdx.x, C::THREADS);
+    RowTwSrc<N, true, C::RES> twf_own;
+    if (!SHARE) twf_own.init(a.tw_fwd, twl + C::TWL_B, t, threadIdx.x, C::THREADS);
+    __syncthreads();
+
+    auto pair_of = [&](int it, bool &valid) { const int pr = (it * gridDim.x + blockIdx.x) * G + grp; valid = pr < npairs; return valid ? 2 * pr : 0; };
+    cf nyqA = cf_make(0.f, 0.f), nyqB = nyqA;
+    if (DMA && iters > 0) {                                   // prologue: phase 0 of the first pair
+        bool v; const int x = pair_of(0, v);
+        row_dma_issue<N, SLAB>(stg, t, a.M, a.M + a.m_fstride, x, x, a.ks, a.m_sstride, nyqA, nyqB);
+    }
+
     for (int it = 0; it < iters; ++it) {
-        const int pr = (it * gridDim.x + blockIdx.x) * G + grp;
-        const bool valid = pr < npairs;
-        const int x0 = valid ? 2 * pr : 0, x1 = x0 + 1;       // invalid groups recompute pair 0, store nothing
+        bool valid;
+        const int x0 = pair_of(it, valid), x1 = x0 + 1;       // invalid groups recompute pair 0, store nothing
         cf reg[16];
-        float t0[16], t1[16];
+        const int t_it = launder(t);   (void)t_it;
 
         if (MODE == ROW_FUSED) {
+            float t0[16];
 #pragma unroll
+            for (int e = 0; e < 16; ++e) t0[e] = 0.f;
+#pragma unroll 1
             for (int r = 0; r < 2; ++r) {
-                const int x = r ? x1 : x0;
+                const int x = x0 + r;
                 float zx[16], zy[16];
-                __syncthreads();
-                row_load_pair<N>(lds, t, a.M, a.M + a.m_fstride, x, x, a.ks, a.m_sstride);
-                __syncthreads();
-                row_fft_bwd<N>(lds, t, a.tw_bwd, reg);
+                // ---- phase (r, 0): dvortdx, dvortdy of row x
+                if (DMA) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    lds_barrier();
+                    row_ext_from_stage<N>(reg, launder(t), stg, nyqA, nyqB);
+                    lds_barrier();
+                    row_dma_issue<N, SLAB>(stg, launder(t), a.M + 2 * a.m_fstride, a.M + 3 * a.m_fstride, x, x, a.ks, a.m_sstride, nyqA, nyqB);
+                } else {
+                    row_load_pair<N, SLAB>(reg, launder(t), a.M, a.M + a.m_fstride, x, x, a.ks, a.m_sstride);
+                }
+                row_fft<N, false>(lds, launder(t), twb, reg);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { zx[q] = reg[q].x * a.scale; zy[q] = reg[q].y * a.scale; }   // main.cpp:154,168
-                __syncthreads();
-                row_load_pair<N>(lds, t, a.M + 2 * a.m_fstride, a.M + 3 * a.m_fstride, x, x, a.ks, a.m_sstride);
-                __syncthreads();
-                row_fft_bwd<N>(lds, t, a.tw_bwd, reg);
+                for (int e = 0; e < 16; ++e) { zx[e] = reg[e].x * a.scale; zy[e] = reg[e].y * a.scale; }   // main.cpp:154,168
+                // ---- phase (r, 1): u, v of row x
+                if (DMA) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    lds_barrier();
+                    row_ext_from_stage<N>(reg, launder(t), stg, nyqA, nyqB);
+                    lds_barrier();
+                    bool vn = true; int xn = x1;
+                    if (r == 1) xn = (it + 1 < iters) ? pair_of(it + 1, vn) : -1;
+                    if (xn >= 0) row_dma_issue<N, SLAB>(stg, launder(t), a.M, a.M + a.m_fstride, xn, xn, a.ks, a.m_sstride, nyqA, nyqB);
+                } else {
+                    row_load_pair<N, SLAB>(reg, launder(t), a.M + 2 * a.m_fstride, a.M + 3 * a.m_fstride, x, x, a.ks, a.m_sstride);
+                }
+                row_fft<N, false>(lds, launder(t), twb, reg);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float u = -(reg[q].x * a.scale);            // main.cpp:200-201
-                    const float v = reg[q].y * a.scale;               // main.cpp:214
-                    const float s = a.src ? a.src[(size_t)x * N + t + q * T] : 0.0f;
-                    const float val = -u * zx[q] - v * zy[q] + s;     // main.cpp:225-227
-                    if (r == 0) t0[q] = val; else t1[q] = val;
+                for (int e = 0; e < 16; ++e) {
+                    const float u = -(reg[e].x * a.scale);            // main.cpp:200-201
+                    const float v = reg[e].y * a.scale;               // main.cpp:214
+                    const float s = a.src ? a.src[(size_t)x * N + t_it + ord_i<RL>(e) * T] : 0.0f;
+                    const float val = -u * zx[e] - v * zy[e] + s;     // main.cpp:225-227
+                    reg[e] = cf_make(t0[e], val);      // complete only after r == 1
+                    t0[e] = val;
                 }
             }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) reg[q] = cf_make(t0[q], t1[q]);
         } else if (MODE == ROW_FWD) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                reg[q] = cf_make(a.rin[(size_t)x0 * N + t + q * T], a.rin[(size_t)x1 * N + t + q * T]);
+            for (int e = 0; e < 16; ++e) {
+                const int y = t_it + ord_i<RL>(e) * T;
+                reg[e] = cf_make(a.rin[(size_t)x0 * N + y], a.rin[(size_t)x1 * N + y]);
+            }
         }
 
         if (MODE == ROW_FUSED || MODE == ROW_FWD) {
-            row_fft_fwd<N>(lds, t, a.tw_fwd, reg);                    // main.cpp:237 (y part)
-            if (valid) row_store_pair<N>(lds, t, a.T, x0, x1, a.ks, a.t_sstride);
+            if constexpr (SHARE) row_fft<N, true>(lds, launder(t), reinterpret_cast<const RowTwSrc<N, true, true> &>(twb), reg);   // main.cpp:237 (y part)
+            else row_fft<N, true>(lds, launder(t), twf_own, reg);
+            row_store_pair<N, SLAB>(lds, launder(t), reg, valid, a.T, x0, x1, a.ks, a.t_sstride);
         } else {
-            __syncthreads();
-            row_load_pair<N>(lds, t, a.M, a.M, x0, x1, a.ks, a.m_sstride);
-            __syncthreads();
-            row_fft_bwd<N>(lds, t, a.tw_bwd, reg);
+            row_load_pair<N, SLAB>(reg, launder(t), a.M, a.M, x0, x1, a.ks, a.m_sstride);
+            row_fft<N, false>(lds, launder(t), twb, reg);
             if (valid) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    a.rout[(size_t)x0 * N + t + q * T] = reg[q].x * a.scale;
-                    a.rout[(size_t)x1 * N + t + q * T] = reg[q].y * a.scale;
+                for (int e = 0; e < 16; ++e) {
+                    const int y = t_it + ord_i<RL>(e) * T;
+                    a.rout[(size_t)x0 * N + y] = reg[e].x * a.scale;
+                    a.rout[(size_t)x1 * N + y] = reg[e].y * a.scale;
                 }
             }
         }

@@ -331,11 +331,12 @@ template <int N, int MODE> static int launch_row_t(fb_ctx *c, const RowArgs &a)
     int grid = (npairs + C::G - 1) / C::G;
     const int cap = c->max_wg / 2;            // ~4 resident workgroups per CU
     if (grid > cap) grid = cap;
-    auto kern = k_row<N, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    const bool slab = a.m_sstride != 0 || a.t_sstride != 0;
+    auto kern = slab ? k_row<N, MODE, true> : k_row<N, MODE, false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[slab]) {
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
+        attr_set[slab] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, c->stream, a);
     HIPCHK(hipGetLastError());
