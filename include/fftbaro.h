@@ -136,6 +136,36 @@ int fb_model_time_steps(fb_model *m, int nsteps, float *total_ms);
 int fb_model_profile_steps(fb_model *m, int nsteps, float *ms_sum, int *launches);
 
 /* ---------------------------------------------------------------------------------------
+ * Slab decomposition over the GPUs of one node (one process per GPU).
+ * No reference counterpart -- the reference is single-process.  Process `rank` of `world`
+ * (a power of two) owns the x rows [rank*XL, (rank+1)*XL), XL = nx/world, of every physical
+ * field and the ky columns [ky0, ky0+KS) of every spectral field (KS = 16*ceil((ny/2+1)/(16*world))).
+ * The engine does the local passes; the CALLER does the two all-to-all transposes per RK stage
+ * (RCCL via torch.distributed, or ncclSend/ncclRecv) on four buffers it owns, E = nx*KS complex:
+ *   w4_send [4][nx][KS]          column-slab layout: written by FB_PH_PRIME / FB_PH_COL_FWD,
+ *                                 finished by FB_PH_COL_BWD; destination d's block of field f is the
+ *                                 contiguous range [f][d*XL .. (d+1)*XL)[KS]
+ *   w4_recv [4][world][XL][KS]   row-slab layout: block s of field f comes from rank s
+ *   t_send  [world][XL][KS]      written by FB_PH_ROW / FB_PH_R2C_ROWS; block d goes to rank d
+ *   t_recv  [nx][KS]             block s (rows s*XL..) comes from rank s
+ * One RK4 step = for stage in 0..3 { COL_BWD; all-to-all(w4, per field); ROW; all-to-all(t); COL_FWD(stage) },
+ * preceded once by PRIME after the state was set.
+ * ------------------------------------------------------------------------------------- */
+int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, int rank, int world);
+int fb_slab_geometry(fb_ctx *ctx, int *rows_local, int *cols_per_slab, int *ky0, size_t *elems_per_field);
+int fb_model_create_slab(fb_model **out, fb_ctx *ctx, float nu, float dt, float *d_w4_send, float *d_w4_recv,
+                         float *d_t_send, float *d_t_recv);
+#define FB_PH_PRIME     0   /* derivatives of the current vort_c -> w4_send                               */
+#define FB_PH_COL_BWD   1   /* backward x sub-pass on w4_send (then transpose w4_send -> w4_recv)          */
+#define FB_PH_ROW       2   /* w4_recv -> c2r rows, Jacobian (+ local rows of vort_src), r2c rows -> t_send */
+#define FB_PH_COL_FWD   3   /* t_recv -> forward x pass, viscosity, mask, RK stage `stage`, derivatives    */
+#define FB_PH_R2C_ROWS  4   /* d_real_in (local rows [XL][ny]) -> t_send           (set_vort, first half)  */
+#define FB_PH_R2C_COLS  5   /* t_recv -> vort_c                                    (set_vort, second half) */
+#define FB_PH_C2R_COLS  6   /* copy of vort_c -> w4_send field 0                   (get_vort, first half)  */
+#define FB_PH_C2R_ROWS  7   /* w4_recv field 0 -> d_real_out (local rows, normalised)                      */
+int fb_model_phase(fb_model *m, int phase, int stage, const float *d_real_in, float *d_real_out);
+
+/* ---------------------------------------------------------------------------------------
  * Field I/O on HOST buffers.  Replaces writeField / readField (fieldio.hpp:5-6,
  * fieldio.cpp:7-33): identical bytes on disk and identical stderr lines, plus a status.
  * ------------------------------------------------------------------------------------- */

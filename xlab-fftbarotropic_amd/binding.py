@@ -79,6 +79,10 @@ def lib():
     L.fb_model_profile_steps.argtypes = [vp, ip, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.fb_make_field.argtypes = [C.c_char_p, ip, ip, C.c_float, C.c_float, C.c_void_p]
     L.fb_make_source_kuo2004.argtypes = [ip, ip, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    L.fb_create_slab.argtypes = [C.POINTER(vp), ip, ip, C.c_float, C.c_float, ip, ip]
+    L.fb_slab_geometry.argtypes = [vp, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip), C.POINTER(C.c_size_t)]
+    L.fb_model_create_slab.argtypes = [C.POINTER(vp), vp, C.c_float, C.c_float, fp, fp, fp, fp]
+    L.fb_model_phase.argtypes = [vp, ip, ip, fp, fp]
     L.fb_write_field.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
     L.fb_read_field.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
     _lib = L
@@ -93,6 +97,7 @@ EXPORTS = [
     "fb_model_create", "fb_model_destroy", "fb_model_set_vort", "fb_model_set_source", "fb_model_step",
     "fb_model_get_vort", "fb_model_get_diag", "fb_model_get_spectrum", "fb_model_set_spectrum", "fb_model_info",
     "fb_model_time_steps", "fb_model_profile_steps", "fb_write_field", "fb_read_field", "fb_make_field", "fb_make_source_kuo2004",
+    "fb_create_slab", "fb_slab_geometry", "fb_model_create_slab", "fb_model_phase",
 ]
 
 

@@ -378,12 +378,13 @@ __global__ void __launch_bounds__(256) k_col_strided(ColArgs a)
 {
     using W = WaveTile<n>;
     __shared__ __attribute__((aligned(16))) cf smem[4 * W::LDS_CF];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wv = threadIdx.x >> 6;
     cf *lds = smem + wv * W::LDS_CF;
-    const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
     const int ntc = a.P >> 4;
     const long ntiles = (long)a.nfields * a.N2 * ntc;
     for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const int lane = launder((int)(threadIdx.x & 63));
+        const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
         const int f = (int)(tile / ((long)a.N2 * ntc));
         const int rem = (int)(tile - (long)f * a.N2 * ntc);
         const int b = rem / ntc, ct = rem - b * ntc;
@@ -413,12 +414,13 @@ __global__ void __launch_bounds__(256) k_col_block(ColArgs a)
 {
     using W = WaveTile<n>;
     __shared__ __attribute__((aligned(16))) cf smem[4 * W::LDS_CF];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wv = threadIdx.x >> 6;
     cf *lds = smem + wv * W::LDS_CF;
-    const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
     const int ntc = a.P >> 4;
     const long ntiles = (long)a.nfields * a.N1 * ntc;
     for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const int lane = launder((int)(threadIdx.x & 63));
+        const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
         const int f = (int)(tile / ((long)a.N1 * ntc));
         const int rem = (int)(tile - (long)f * a.N1 * ntc);
         const int cb = rem / ntc, ct = rem - cb * ntc;
@@ -483,34 +485,33 @@ struct MidArgs {
 };
 
 template <int n>
-__global__ void __launch_bounds__(256) k_col_mid(MidArgs a)
+__global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(MidArgs a)
 {
     using W = WaveTile<n>;
     __shared__ __attribute__((aligned(16))) cf smem[4 * W::LDS_CF];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wv = threadIdx.x >> 6;
     cf *lds = smem + wv * W::LDS_CF;
-    const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
     const int ntc = a.P >> 4;
     const long ntiles = (long)a.N1 * ntc;
-    const bool lb = W::lb_active(lane);
     for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
+        // per-tile opaque lane id: keeps address/coefficient arithmetic out of loop-invariant registers
+        const int lane = launder((int)(threadIdx.x & 63));
+        const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
+        const bool lb = W::lb_active(lane);
         const int cb = (int)(tile / ntc), ct = (int)(tile - (long)cb * ntc);
         const size_t tbase = (size_t)cb * n * a.P + ct * 16;
-        cf wbig[W::NLA];
-#pragma unroll
-        for (int m = 0; m < W::NLA; ++m) wbig[m] = a.tw_big[(g + 8 * m) * cb];
-
-        cf zn[W::NLB];                       // state the derivatives are taken of (LB layout)
         const int col = ct * 16 + c, ky = a.ky0 + col;
         const float gy = a.coef.gy[ky];
         const double ky2 = a.coef.ky2[ky];
 
+        cf zn[W::NLB];                       // state the derivatives are taken of (LB layout)
         if (a.stage >= 0) {
             float4 in[W::NLA];
 #pragma unroll
             for (int m = 0; m < W::NLA; ++m) {
                 float4 v = *reinterpret_cast<const float4 *>(a.Tin + tbase + (size_t)(g + 8 * m) * a.P + 2 * cp);
-                cf p0 = cmul(cf_make(v.x, v.y), wbig[m]), p1 = cmul(cf_make(v.z, v.w), wbig[m]);
+                const cf wb = a.tw_big[(g + 8 * m) * cb];
+                cf p0 = cmul(cf_make(v.x, v.y), wb), p1 = cmul(cf_make(v.z, v.w), wb);
                 in[m] = make_float4(p0.x, p0.y, p1.x, p1.y);
             }
             cf th[W::NLB];
@@ -557,32 +558,42 @@ __global__ void __launch_bounds__(256) k_col_mid(MidArgs a)
                     zn[s * 8 + q] = a.Zbase[tbase + (size_t)(h + 4 * s + W::R1 * q) * a.P + c];
         }
 
-        // four derivatives of zn, each through the backward block sub-pass
-#pragma unroll
+        // derivatives of zn through the backward block sub-pass: f0 gradx(vort), f1 grady(vort),
+        // then zn <- psi = invertLaplacian(vort) in place, f2 grady(psi), f3 gradx(psi)
+#pragma unroll 1
         for (int f = 0; f < 4; ++f) {
+            const int lf = launder(lane);
+            const int gf = lf >> 3, cpf = lf & 7, hf = lf >> 4;
             cf fld[W::NLB];
             if (lb) {
+                if (f == 2) {
+#pragma unroll
+                    for (int s = 0; s < W::NP; ++s)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {                 // main.cpp:179, fftwfop.cpp:112-117
+                            const int e = s * 8 + q, d = hf + 4 * s + W::R1 * q, ikx = cb + a.N1 * d;
+                            const float li = (ikx == 0 && ky == 0) ? 1.0f : (float)(-(a.coef.kx2[ikx] + ky2));
+                            zn[e] = (ky < a.coef.hy) ? cf_make(zn[e].x / li, zn[e].y / li) : cf_make(0.f, 0.f);
+                        }
+                }
+                const bool use_gx = (f == 0 || f == 3);
 #pragma unroll
                 for (int s = 0; s < W::NP; ++s)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const int e = s * 8 + q, d = h + 4 * s + W::R1 * q, ikx = cb + a.N1 * d;
-                        cf z = zn[e];
-                        if (f >= 2) {          // psi_c = invertLaplacian(vort_c)   main.cpp:179, fftwfop.cpp:112-117
-                            const float li = (ikx == 0 && ky == 0) ? 1.0f : (float)(-(a.coef.kx2[ikx] + ky2));
-                            z = (ky < a.coef.hy) ? cf_make(z.x / li, z.y / li) : cf_make(0.f, 0.f);
-                        }
-                        const float kk = (f == 0 || f == 3) ? a.coef.gx[ikx] : gy;   // f0 gradx(vort) f1 grady(vort) f2 grady(psi) f3 gradx(psi)
-                        fld[e] = cf_make(-z.y * kk, z.x * kk);                        // fftwfop.cpp:87-103
+                        const int e = s * 8 + q, d = hf + 4 * s + W::R1 * q, ikx = cb + a.N1 * d;
+                        const float kk = use_gx ? a.coef.gx[ikx] : gy;
+                        fld[e] = cf_make(-zn[e].y * kk, zn[e].x * kk);                // fftwfop.cpp:87-103
                     }
             }
             float4 out[W::NLA];
-            wave_fft_B2A<n, +1>(fld, out, lds, a.tw_n, lane);
+            wave_fft_B2A<n, +1>(fld, out, lds, a.tw_n, lf);
             cf *dst = a.W4 + (size_t)f * a.fstride + tbase;
 #pragma unroll
             for (int m = 0; m < W::NLA; ++m) {
-                cf p0 = cmulc(cf_make(out[m].x, out[m].y), wbig[m]), p1 = cmulc(cf_make(out[m].z, out[m].w), wbig[m]);
-                *reinterpret_cast<float4 *>(dst + (size_t)(g + 8 * m) * a.P + 2 * cp) = make_float4(p0.x, p0.y, p1.x, p1.y);
+                const cf wb = a.tw_big[(gf + 8 * m) * cb];
+                cf p0 = cmulc(cf_make(out[m].x, out[m].y), wb), p1 = cmulc(cf_make(out[m].z, out[m].w), wb);
+                *reinterpret_cast<float4 *>(dst + (size_t)(gf + 8 * m) * a.P + 2 * cpf) = make_float4(p0.x, p0.y, p1.x, p1.y);
             }
         }
     }

@@ -49,7 +49,9 @@ extern "C" int fb_size_supported(int nx, int ny)
 // context
 // --------------------------------------------------------------------------------------------
 struct fb_ctx {
-    int nx, ny, hy, P;          // P = pitch of the private layouts (complex)
+    int world, rank;            // slab decomposition: this process owns x rows [rank*XL, (rank+1)*XL) and
+    int XL, ky0;                //   ky columns [ky0, ky0+P); world == 1: everything
+    int nx, ny, hy, P;          // P = pitch of the private layouts (complex) == columns per slab
     int N1, N2;                 // nx = N1*N2
     float lx, ly;
     hipStream_t stream;
@@ -142,10 +144,14 @@ template <typename T> static int upload(T **dptr, const std::vector<T> &h)
     return FB_OK;
 }
 
-extern "C" int fb_create(fb_ctx **out, int nx, int ny, float lx, float ly)
+extern "C" int fb_create(fb_ctx **out, int nx, int ny, float lx, float ly) { return fb_create_slab(out, nx, ny, lx, ly, 0, 1); }
+
+extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, int rank, int world)
 {
     if (!out) return fail(FB_EINVAL, "fb_create: out is NULL");
     *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || !is_pow2(world) || (nx / world) < 2)
+        return fail(FB_EINVAL, "fb_create_slab: world must be a power of two with nx/world >= 2, 0 <= rank < world");
     if (!fb_size_supported(nx, ny))
         return fail(FB_EUNSUPPORTED, "fb_create: nx, ny must be powers of two in [64, 16384]");
     if (!(lx > 0.f) || !(ly > 0.f)) return fail(FB_EINVAL, "fb_create: Lx, Ly must be positive");
@@ -154,14 +160,18 @@ extern "C" int fb_create(fb_ctx **out, int nx, int ny, float lx, float ly)
         return fail(FB_EHIP, "fb_create: no HIP device (this engine has no CPU fallback)");
 
     fb_ctx *c = new fb_ctx();
-    c->nx = nx; c->ny = ny; c->hy = ny / 2 + 1; c->P = (c->hy + 15) / 16 * 16;
+    c->nx = nx; c->ny = ny; c->hy = ny / 2 + 1;
+    c->world = world; c->rank = rank; c->XL = nx / world;
+    c->P = (c->hy + 16 * world - 1) / (16 * world) * 16;       // columns per slab, multiple of 16
+    c->ky0 = rank * c->P;
+    const int Ptot = c->P * world;
     split_nx(nx, c->N1, c->N2);
     c->lx = lx; c->ly = ly; c->stream = nullptr; c->d_scratch = nullptr;
 
     // ---- coefficient tables: fftwfop.cpp:5-79 ----
     const float TWOPI = (float)(acosf(-1.0f) * 2.0f);                  // fftwfop.hpp:7
     const int hx = nx / 2 + 1;
-    c->h_gx.assign(nx, 0.f); c->h_kx2.assign(nx, 0.0); c->h_gy.assign(c->P, 0.f); c->h_ky2.assign(c->P, 0.0);
+    c->h_gx.assign(nx, 0.f); c->h_kx2.assign(nx, 0.0); c->h_gy.assign(Ptot, 0.f); c->h_ky2.assign(Ptot, 0.0);
     for (int i = 0; i < hx; ++i) c->h_gx[i] = TWOPI * ((float)i) / lx;            // :15-17
     for (int i = hx; i < nx; ++i) c->h_gx[i] = -c->h_gx[nx - i];                  // :18-20
     for (int j = 0; j < c->hy; ++j) c->h_gy[j] = TWOPI * ((float)j) / ly;         // :22-24
@@ -180,7 +190,9 @@ extern "C" int fb_create(fb_ctx **out, int nx, int ny, float lx, float ly)
         delete c; return rc;
     }
     hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, 0));
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
     c->max_wg = prop.multiProcessorCount * 8;
     *out = c;
     return FB_OK;
@@ -263,9 +275,12 @@ static int grid_for(const fb_ctx *c, size_t n, int block = 256)
     return (int)(g ? g : 1);
 }
 
+#define NEED_SINGLE(c) do { if ((c)->world != 1) return fail(FB_EINVAL, "natural-layout entry point on a slab context (world > 1)"); } while (0)
+
 template <int OP> static int launch_op(fb_ctx *c, const float *in, float *out)
 {
     if (!c || !in || !out) return fail(FB_EINVAL, "operator: NULL argument");
+    NEED_SINGLE(c);
     const size_t total = (size_t)c->nx * c->hy;
     hipLaunchKernelGGL((k_spec_op<OP>), dim3(grid_for(c, total)), dim3(256), 0, c->stream, make_coef(c), (const cf *)in, (cf *)out, c->hy, total);
     HIPCHK(hipGetLastError());
@@ -432,7 +447,8 @@ static int ensure_scratch(fb_ctx *c)
 static RowArgs row_args_base(const fb_ctx *c)
 {
     RowArgs a; memset(&a, 0, sizeof(a));
-    a.ks = c->P; a.m_sstride = 0; a.t_sstride = 0; a.nx = c->nx; a.tw_bwd = c->d_tw_row_bwd; a.tw_fwd = c->d_tw_row_fwd;
+    const long ss = c->world > 1 ? (long)c->XL * c->P : 0;       // slab stride of the transpose buffers
+    a.ks = c->P; a.m_sstride = ss; a.t_sstride = ss; a.nx = c->XL; a.tw_bwd = c->d_tw_row_bwd; a.tw_fwd = c->d_tw_row_fwd;
     return a;
 }
 
@@ -468,6 +484,7 @@ static int relayout(fb_ctx *c, const cf *in, cf *out, bool to_private)
 extern "C" int fb_r2c(fb_ctx *c, const float *d_in, float *d_out)
 {
     if (!c || !d_in || !d_out) return fail(FB_EINVAL, "fb_r2c: NULL");
+    NEED_SINGLE(c);
     int rc;
     if ((rc = ensure_scratch(c))) return rc;
     HIPCHK(hipMemsetAsync(c->d_scratch, 0, priv_elems(c) * sizeof(cf), c->stream));
@@ -478,6 +495,7 @@ extern "C" int fb_r2c(fb_ctx *c, const float *d_in, float *d_out)
 extern "C" int fb_c2r(fb_ctx *c, const float *d_in, float *d_out, int normalize)
 {
     if (!c || !d_in || !d_out) return fail(FB_EINVAL, "fb_c2r: NULL");
+    NEED_SINGLE(c);
     int rc;
     if ((rc = ensure_scratch(c))) return rc;
     if ((rc = relayout(c, (const cf *)d_in, c->d_scratch, true))) return rc;
@@ -492,34 +510,73 @@ struct fb_model {
     fb_ctx *c;
     float nu, dt;
     cf *ZA, *ZB, *ACC, *TT, *W4;    // private layouts, nx*P complex each (W4: 4 of them)
+    // slab mode: the four transpose buffers are the caller's (torch tensors handed to RCCL);
+    // world == 1: w4_recv == w4_send == W4 and t_send == t_recv == TT (no exchange)
+    cf *w4_send, *w4_recv, *t_send, *t_recv;
+    bool own_buffers;
     float *src;                      // vort_src or NULL (== zeros)
     cf *nat[3];                      // natural-layout temporaries for the record path (lazy)
     bool primed;                     // W4 holds the block-backward derivatives of ZA
 };
 
-extern "C" int fb_model_create(fb_model **out, fb_ctx *c, float nu, float dt)
+static int model_create_impl(fb_model **out, fb_ctx *c, float nu, float dt, bool own)
 {
     if (!out || !c) return fail(FB_EINVAL, "fb_model_create: NULL");
     *out = nullptr;
     fb_model *m = new fb_model();
     memset(m, 0, sizeof(*m));
-    m->c = c; m->nu = nu; m->dt = dt;
+    m->c = c; m->nu = nu; m->dt = dt; m->own_buffers = own;
     const size_t n = priv_elems(c) * sizeof(cf);
-    cf **arr[] = {&m->ZA, &m->ZB, &m->ACC, &m->TT};
+    cf **arr[] = {&m->ZA, &m->ZB, &m->ACC};
     for (auto p : arr) {
         if (hipMalloc((void **)p, n) != hipSuccess) { fb_model_destroy(m); return fail(FB_ENOMEM, "model allocation failed"); }
         hipMemsetAsync(*p, 0, n, c->stream);
     }
-    if (hipMalloc((void **)&m->W4, 4 * n) != hipSuccess) { fb_model_destroy(m); return fail(FB_ENOMEM, "model allocation failed"); }
-    hipMemsetAsync(m->W4, 0, 4 * n, c->stream);
+    if (own) {
+        if (hipMalloc((void **)&m->TT, n) != hipSuccess || hipMalloc((void **)&m->W4, 4 * n) != hipSuccess) {
+            fb_model_destroy(m); return fail(FB_ENOMEM, "model allocation failed");
+        }
+        hipMemsetAsync(m->TT, 0, n, c->stream);
+        hipMemsetAsync(m->W4, 0, 4 * n, c->stream);
+        m->w4_send = m->w4_recv = m->W4; m->t_send = m->t_recv = m->TT;
+    }
     *out = m;
+    return FB_OK;
+}
+
+extern "C" int fb_model_create(fb_model **out, fb_ctx *c, float nu, float dt)
+{
+    if (c && c->world != 1) return fail(FB_EINVAL, "fb_model_create on a slab context: use fb_model_create_slab");
+    return model_create_impl(out, c, nu, dt, true);
+}
+
+extern "C" int fb_model_create_slab(fb_model **out, fb_ctx *c, float nu, float dt, float *d_w4_send, float *d_w4_recv,
+                                    float *d_t_send, float *d_t_recv)
+{
+    if (!d_w4_send || !d_w4_recv || !d_t_send || !d_t_recv) return fail(FB_EINVAL, "fb_model_create_slab: NULL buffer");
+    int rc = model_create_impl(out, c, nu, dt, false);
+    if (rc) return rc;
+    fb_model *m = *out;
+    m->w4_send = (cf *)d_w4_send; m->w4_recv = (cf *)d_w4_recv; m->t_send = (cf *)d_t_send; m->t_recv = (cf *)d_t_recv;
+    m->W4 = m->w4_send; m->TT = m->t_recv;
+    return FB_OK;
+}
+
+extern "C" int fb_slab_geometry(fb_ctx *c, int *rows_local, int *cols_per_slab, int *ky0, size_t *elems_per_field)
+{
+    if (!c) return fail(FB_EINVAL, "ctx NULL");
+    if (rows_local) *rows_local = c->XL;
+    if (cols_per_slab) *cols_per_slab = c->P;
+    if (ky0) *ky0 = c->ky0;
+    if (elems_per_field) *elems_per_field = priv_elems(c);
     return FB_OK;
 }
 
 extern "C" int fb_model_destroy(fb_model *m)
 {
     if (!m) return FB_OK;
-    hipFree(m->ZA); hipFree(m->ZB); hipFree(m->ACC); hipFree(m->TT); hipFree(m->W4);
+    hipFree(m->ZA); hipFree(m->ZB); hipFree(m->ACC);
+    if (m->own_buffers) { hipFree(m->TT); hipFree(m->W4); }
     if (m->src) hipFree(m->src);
     for (auto p : m->nat) if (p) hipFree(p);
     delete m;
@@ -539,6 +596,7 @@ extern "C" int fb_model_set_vort(fb_model *m, const float *d_vort)
 {
     if (!m || !d_vort) return fail(FB_EINVAL, "fb_model_set_vort: NULL");
     fb_ctx *c = m->c;
+    NEED_SINGLE(c);
     HIPCHK(hipMemsetAsync(m->ZA, 0, priv_elems(c) * sizeof(cf), c->stream));
     m->primed = false;
     return r2c_private(c, d_vort, m->ZA);                   // main.cpp:256
@@ -548,7 +606,7 @@ extern "C" int fb_model_set_source(fb_model *m, const float *d_src)
 {
     if (!m) return fail(FB_EINVAL, "model NULL");
     fb_ctx *c = m->c;
-    const size_t n = (size_t)c->nx * c->ny * sizeof(float);
+    const size_t n = (size_t)c->XL * c->ny * sizeof(float);       // the caller's local rows
     if (!d_src) { if (m->src) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(m->src); m->src = nullptr; } return FB_OK; }
     if (!m->src && hipMalloc((void **)&m->src, n) != hipSuccess) return fail(FB_ENOMEM, "source allocation failed");
     HIPCHK(hipMemcpyAsync(m->src, d_src, n, hipMemcpyDeviceToDevice, c->stream));
@@ -559,8 +617,8 @@ static MidArgs mid_args(fb_model *m, int stage)
 {
     fb_ctx *c = m->c;
     MidArgs a;
-    a.Tin = m->TT; a.Zbase = m->ZA; a.Zcur = m->ZB; a.Acc = m->ACC; a.Zout = m->ZA; a.W4 = m->W4;
-    a.fstride = (long)priv_elems(c); a.P = c->P; a.N1 = c->N1; a.N2 = c->N2; a.ky0 = 0; a.stage = stage;
+    a.Tin = m->t_recv; a.Zbase = m->ZA; a.Zcur = m->ZB; a.Acc = m->ACC; a.Zout = m->ZA; a.W4 = m->w4_send;
+    a.fstride = (long)priv_elems(c); a.P = c->P; a.N1 = c->N1; a.N2 = c->N2; a.ky0 = c->ky0; a.stage = stage;
     a.nu = m->nu; a.dt = m->dt; a.coef = make_coef(c); a.tw_n = c->d_tw_n2; a.tw_big = c->d_tw_big;
     return a;
 }
@@ -580,6 +638,7 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
 {
     if (!m || nsteps < 0) return fail(FB_EINVAL, "fb_model_step: bad argument");
     fb_ctx *c = m->c;
+    if (c->world != 1) return fail(FB_EINVAL, "fb_model_step on a slab model: drive it with fb_model_phase + all-to-all");
     int rc;
     if (nsteps == 0) return FB_OK;
     if (!m->primed) {
@@ -590,15 +649,15 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
     for (int s = 0; s < nsteps; ++s) {
         for (int k = 0; k < 4; ++k) {
             PROF_BEGIN(0);
-            if ((rc = launch_col_strided<+1>(c, m->W4, 4, (long)priv_elems(c)))) return rc;
+            if ((rc = launch_col_strided<+1>(c, m->w4_send, 4, (long)priv_elems(c)))) return rc;
             PROF_END(0);
             RowArgs a = row_args_base(c);
-            a.M = m->W4; a.m_fstride = (long)priv_elems(c); a.T = m->TT; a.src = m->src; a.scale = scale;
+            a.M = m->w4_recv; a.m_fstride = (long)priv_elems(c); a.T = m->t_send; a.src = m->src; a.scale = scale;
             PROF_BEGIN(1);
             if ((rc = launch_row<ROW_FUSED>(c, a))) return rc;
             PROF_END(1);
             PROF_BEGIN(2);
-            if ((rc = launch_col_strided<-1>(c, m->TT, 1, 0))) return rc;
+            if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0))) return rc;
             PROF_END(2);
             PROF_BEGIN(3);
             if ((rc = launch_col_mid(c, mid_args(m, k)))) return rc;
@@ -609,6 +668,54 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
 }
 
 extern "C" int fb_model_step(fb_model *m, int nsteps) { return model_step_impl(m, nsteps, nullptr); }
+
+// One phase of the slab-decomposed step; the caller performs the all-to-all transposes between
+// phases (see include/fftbaro.h).  Valid for world == 1 too (then no exchange is needed).
+extern "C" int fb_model_phase(fb_model *m, int phase, int stage, const float *d_real_in, float *d_real_out)
+{
+    if (!m) return fail(FB_EINVAL, "model NULL");
+    fb_ctx *c = m->c;
+    const long E = (long)priv_elems(c);
+    const float scale = 1.0f / (float)((size_t)c->nx * c->ny);
+    int rc;
+    switch (phase) {
+    case FB_PH_PRIME:                                       // derivatives of vort_c -> w4_send (block sub-pass done)
+        m->primed = true;
+        return launch_col_mid(c, mid_args(m, -1));
+    case FB_PH_COL_BWD:                                     // strided backward sub-pass on the 4 fields (in w4_send)
+        return launch_col_strided<+1>(c, m->w4_send, 4, E);
+    case FB_PH_ROW: {                                       // w4_recv (row slabs) -> tendency rows in t_send
+        RowArgs a = row_args_base(c);
+        a.M = m->w4_recv; a.m_fstride = E; a.T = m->t_send; a.src = m->src; a.scale = scale;
+        return launch_row<ROW_FUSED>(c, a);
+    }
+    case FB_PH_COL_FWD:                                     // t_recv (column slab) -> forward x pass + RK update + derivatives
+        if (stage < 0 || stage > 3) return fail(FB_EINVAL, "fb_model_phase: stage");
+        if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0))) return rc;
+        return launch_col_mid(c, mid_args(m, stage));
+    case FB_PH_R2C_ROWS: {                                  // local real rows -> y-transformed rows in t_send
+        if (!d_real_in) return fail(FB_EINVAL, "fb_model_phase: d_real_in NULL");
+        RowArgs a = row_args_base(c); a.rin = d_real_in; a.T = m->t_send;
+        return launch_row<ROW_FWD>(c, a);
+    }
+    case FB_PH_R2C_COLS:                                    // t_recv -> vort_c (private layout)
+        if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0)) || (rc = launch_col_block<-1>(c, m->t_recv, 1, 0))) return rc;
+        HIPCHK(hipMemcpyAsync(m->ZA, m->t_recv, E * sizeof(cf), hipMemcpyDeviceToDevice, c->stream));
+        m->primed = false;
+        return FB_OK;
+    case FB_PH_C2R_COLS:                                    // copy of vort_c -> x-inverse-transformed columns in w4_send[0]
+        HIPCHK(hipMemcpyAsync(m->w4_send, m->ZA, E * sizeof(cf), hipMemcpyDeviceToDevice, c->stream));
+        m->primed = false;                                  // w4_send is clobbered
+        if ((rc = launch_col_block<+1>(c, m->w4_send, 1, 0))) return rc;
+        return launch_col_strided<+1>(c, m->w4_send, 1, 0);
+    case FB_PH_C2R_ROWS: {                                  // w4_recv[0] (row slabs) -> normalised real rows
+        if (!d_real_out) return fail(FB_EINVAL, "fb_model_phase: d_real_out NULL");
+        RowArgs a = row_args_base(c); a.M = m->w4_recv; a.m_fstride = E; a.rout = d_real_out; a.scale = scale;
+        return launch_row<ROW_INV>(c, a);
+    }
+    }
+    return fail(FB_EINVAL, "fb_model_phase: unknown phase");
+}
 
 extern "C" int fb_model_time_steps(fb_model *m, int nsteps, float *total_ms)
 {
@@ -646,12 +753,14 @@ extern "C" int fb_model_profile_steps(fb_model *m, int nsteps, float *ms_sum, in
 extern "C" int fb_model_get_spectrum(fb_model *m, float *d_spec)
 {
     if (!m || !d_spec) return fail(FB_EINVAL, "fb_model_get_spectrum: NULL");
+    NEED_SINGLE(m->c);
     return relayout(m->c, m->ZA, (cf *)d_spec, false);
 }
 
 extern "C" int fb_model_set_spectrum(fb_model *m, const float *d_spec)
 {
     if (!m || !d_spec) return fail(FB_EINVAL, "fb_model_set_spectrum: NULL");
+    NEED_SINGLE(m->c);
     m->primed = false;
     return relayout(m->c, (const cf *)d_spec, m->ZA, true);
 }
@@ -660,6 +769,7 @@ extern "C" int fb_model_get_vort(fb_model *m, float *d_vort)
 {
     if (!m || !d_vort) return fail(FB_EINVAL, "fb_model_get_vort: NULL");
     fb_ctx *c = m->c;
+    NEED_SINGLE(c);
     int rc;
     if ((rc = ensure_scratch(c))) return rc;
     // copy of vort_c (main.cpp:273), c2r, normalise (main.cpp:275)
@@ -671,6 +781,7 @@ extern "C" int fb_model_get_diag(fb_model *m, float *d_psi, float *d_u, float *d
 {
     if (!m) return fail(FB_EINVAL, "model NULL");
     fb_ctx *c = m->c;
+    NEED_SINGLE(c);
     const size_t n = (size_t)c->nx * c->hy * sizeof(cf);
     for (auto &p : m->nat)
         if (!p && hipMalloc((void **)&p, n) != hipSuccess) return fail(FB_ENOMEM, "record-path allocation failed");
