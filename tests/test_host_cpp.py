@@ -1,0 +1,127 @@
+"""C++ host side of the boundary on the GPU: the drop-in RK4 driver (host/barotropic_main.cpp,
+mirror of main.cpp / main-shallow-water.cpp) and reference-shaped operator code through the
+header-only shim (host/fftwfop_hip.hpp, mirror of fftwfop.hpp)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HOST = os.path.join(ROOT, "xlab-fftbarotropic_amd", "host")
+
+
+def _build():
+    subprocess.check_call(["make", "-s", "-C", HOST])
+
+
+def test_host_programs_link():
+    """CPU-side check: both host programs compile and link against the C ABI."""
+    import xlab_fftbarotropic_amd as X
+    X.build_lib()
+    _build()
+    for exe in ("barotropic_main.out", "shim_check.out"):
+        assert os.access(os.path.join(HOST, exe), os.X_OK)
+
+
+@pytest.mark.gpu
+def test_shim_reference_shaped_tendency(tmp_path):
+    import oracle_py as O
+    import ref_numpy as R
+    _build()
+    n = 256
+    v0 = O.make_field("elliptic", n)
+    (tmp_path / "input").mkdir()
+    v0.tofile(str(tmp_path / "input" / "initial_vorticity.bin"))
+    out = str(tmp_path / "rk1.bin")
+    subprocess.check_call([os.path.join(HOST, "shim_check.out"), str(tmp_path / "input" / "initial_vorticity.bin"), out],
+                          stderr=subprocess.DEVNULL)
+    got = np.fromfile(out, dtype="<f4")
+    ops = O.Operators(n, n, 6e5, 6e5)
+    vc = O.r2c(v0)
+    g = np.float32(n * n)
+    dzdx = O.c2r(ops.gradx(vc), n) / g
+    dzdy = O.c2r(ops.grady(vc), n) / g
+    psi = ops.invertLaplacian(vc)
+    u = -(O.c2r(ops.grady(psi), n) / g)
+    v = O.c2r(ops.gradx(psi), n) / g
+    t = -u * dzdx - v * dzdy + np.float32(0)
+    tc = O.r2c(t)
+    tc = (tc.view(np.float32) + ops.laplacian(vc).view(np.float32) * np.float32(6.5)).view(np.complex64)
+    want = ops.dealiase(tc).view(np.float32).ravel()
+    assert R.rel_l2(got, want) < 1e-5
+
+
+@pytest.mark.gpu
+def test_driver_outputs_match_oracle(tmp_path):
+    """256^2 elliptic vortex (config 1 grid), 250 steps: files, ./log and stdout as main.cpp writes them."""
+    import oracle_py as O
+    import ref_numpy as R
+    _build()
+    n, steps = 256, 250
+    (tmp_path / "in").mkdir()
+    (tmp_path / "out").mkdir()
+    v0 = O.make_field("elliptic", n)
+    v0.tofile(str(tmp_path / "in" / "init.bin"))
+    res = subprocess.run([os.path.join(HOST, "barotropic_main.out"), "-I", "in", "-O", "out", "-i", "init.bin",
+                          "--npts", str(n), "--steps", str(steps)], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, check=True, text=True)
+    lines = res.stdout.splitlines()
+    assert "Start project." in lines and lines[-1] == "Program ends. Congrats!"
+    assert "# Step 0, time = 0.00, record now!" in lines and "# Step 1, time = 3.00" in lines
+    assert "# Step 200, time = 600.00, record now!" in lines
+    log = (tmp_path / "log").read_text().split()
+    exp = []
+    for s in (0, 100, 200):
+        exp += ["out/%s_step_%d.bin" % (name, s) for name in ("vort_src_input", "vort", "psi", "u", "v")]
+    assert log == exp                                            # main.cpp:160-278 order
+    assert "Output out/vort_step_0.bin" in res.stderr            # fieldio.cpp:18
+    rd = lambda name: np.fromfile(str(tmp_path / "out" / name), dtype="<f4").reshape(n, n)
+    assert not rd("vort_src_input_step_0.bin").any()
+    m = O.Model(n, n)
+    m.set_vort(v0)
+    for s in (0, 100, 200):
+        psi, u, v = m.diag()
+        assert R.rel_l2(rd("vort_step_%d.bin" % s), m.vort()) < 1e-5
+        assert R.rel_l2(rd("psi_step_%d.bin" % s), psi) < 1e-5
+        assert R.rel_l2(rd("u_step_%d.bin" % s), u) < 1e-5
+        assert R.rel_l2(rd("v_step_%d.bin" % s), v) < 1e-5
+        m.step(100)
+
+
+@pytest.mark.gpu
+def test_driver_fifo_source(tmp_path):
+    """main-shallow-water.cpp path: per step one flag byte, GRIDS float32 after a flag of 1
+    (vorticity_source.cpp:112-133); the producer closes early so the last reads hit EOF."""
+    import oracle_py as O
+    import ref_numpy as R
+    _build()
+    n, steps = 128, 12
+    (tmp_path / "input").mkdir()
+    (tmp_path / "output").mkdir()
+    v0 = O.make_field("kuo2004", n)
+    v0.tofile(str(tmp_path / "input" / "initial_vorticity.bin"))
+    src = np.zeros((n, n), dtype=np.float32)
+    O.add_cake(src, 6e5, 6e5, 6e5 / 2 + 5e4, 6e5 / 2, 3e-3 / 10800.0, 3e4)
+    stream = b"\x00" * 3 + b"\x01" + src.tobytes() + b"\x00" * 4 + b"\x01" + np.zeros_like(src).tobytes() + b"\x00"
+    fifo = str(tmp_path / "vort_src_fifo")
+    os.mkfifo(fifo)
+    p = subprocess.Popen([os.path.join(HOST, "barotropic_main.out"), "-f", fifo, "--npts", str(n), "--steps", str(steps),
+                          "--record-step", "6"], cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    with open(fifo, "wb") as f:
+        f.write(stream)
+    assert p.wait(timeout=120) == 0
+    m = O.Model(n, n)
+    m.set_vort(v0)
+    for step in range(steps):
+        if step == 6:
+            got = np.fromfile(str(tmp_path / "output" / "vort_step_6.bin"), dtype="<f4").reshape(n, n)
+            assert R.rel_l2(got, m.vort()) < 1e-5
+            s6 = np.fromfile(str(tmp_path / "output" / "vort_src_input_step_6.bin"), dtype="<f4").reshape(n, n)
+            assert np.array_equal(s6, src)                       # dumped before this step's read, source switched on at step 3
+        if step == 3:
+            m.set_source(src)
+        if step == 8:
+            m.set_source(None)
+        m.step(1)
