@@ -247,3 +247,24 @@ def test_errors(X):
     assert Lb.fb_gradx(None, None, None) == 1
     with pytest.raises(X.FftBaroError):
         X.read_field("/nonexistent/file.bin", 4)
+
+
+@pytest.mark.parametrize("n,kind", [(256, "elliptic"), (1024, "elliptic")])
+def test_1000_steps_tolerance(X, O, R, n, kind):
+    """BASELINE.json configs[0]/[1]: elliptic vortex, 1000 RK4 steps, dt = 3 s; north_star bar:
+    vorticity within 1e-5 relative L2 of the CPU reference path (here: the oracle, all host cores)."""
+    v0 = O.make_field(kind, n)
+    m = X.Model(n, n)
+    m.set_vort(v0)
+    m.step(1000)
+    got = m.vort().cpu().numpy()
+    mo = O.Model(n, n)
+    mo.set_vort(v0)
+    mo.step(1000)
+    want = mo.vort()
+    err = R.rel_l2(got, want)
+    print("n=%d: rel L2 after 1000 steps = %.3e, max abs = %.3e" % (n, err, float(np.abs(got - want).max())))
+    assert err < 1e-5
+    psi, u, v = [a.cpu().numpy() for a in m.diag()]
+    po, uo, vo = mo.diag()
+    assert R.rel_l2(u, uo) < 1e-5 and R.rel_l2(v, vo) < 1e-5 and R.rel_l2(psi, po) < 1e-5
