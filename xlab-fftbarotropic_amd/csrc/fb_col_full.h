@@ -1,0 +1,290 @@
+// fb_col_full.h -- single-pass x-transform + spectral update for nx = 4096 (one GPU).
+//
+// Replaces the three column kernels of a stage (k_col_strided<-1>, k_col_mid, k_col_strided<+1>:
+// 20 C of HBM traffic) by one kernel that moves 10 C: a 1024-thread workgroup keeps a whole tile of
+// 8 ky-columns x 4096 x-rows (256 KiB) in its registers and runs the length-4096 transforms as
+// 16 x 16 x 16 with one cross-wave and one in-wave LDS exchange per transform.
+//
+//   thread (w = wave 0..15, l = (lane>>2) 0..15, c = lane&3) holds, for columns 2c,2c+1 of the tile:
+//     mixed space   : rows x = 256 i + 16 w + l,            register index i  = 0..15
+//     spectral space: kx   = k1 + 16 k2 + 256 k3, k1 = w, k2 = l, register index k3 = 0..15
+//   forward : radix-16 over i -> k1 | x W256^{w k1} | wave<->reg transpose | radix-16 over w -> k2 |
+//             x W4096^{l (k1+16 k2)} | lane<->reg transpose | radix-16 over l -> k3
+//   backward: the same steps reversed with conjugated twiddles.
+//
+// Row segments in HBM are 64 B (8 columns); workgroups handling adjacent tiles are placed on the
+// same XCD so that the two halves of every 128-B line meet in one L2 (tools/mb_strided.hip:
+// 3.8-3.9 TB/s with that placement against 2.6-3.0 TB/s without).
+//
+// The ky = ny/2 column is not handled here: on square grids it lies outside the dealiasing circle
+// (fftwfop.cpp:57-61), so its tendency is always masked, its state never changes (SURVEY note N1)
+// and its four derivative columns in W4 stay what the priming pass wrote.  That makes the column
+// count a power of two (ny/2 = 256 tiles of 8 at 4096^2: one tile per CU, no tail).
+//
+// State arrays (ZA, ZB, ACC) use a layout private to this kernel:
+//   [tile][k3][thread] float4 = (column 2c, column 2c+1)   -- fully coalesced, 16 B per lane.
+#pragma once
+#include "fb_kernels.h"
+
+#define CF_THREADS 1024
+#define CF_X1_CF 16384                   /* cross-wave exchange: [k1][w][lane] complex             */
+#define CF_X2_STR 68                     /* in-wave exchange: [reg][l][c] with 4 complex pad / reg */
+#define CF_X2_CF (16 * 16 * CF_X2_STR)
+#define CF_LDS_CF (CF_X2_CF + 512)       /* + tabB[256] (W256^m) + tabA[256] (W4096^m, m < 256)    */
+#define CF_LDS_BYTES (CF_LDS_CF * 8)
+
+struct FullArgs {
+    const cf *Tin;        // tendency after the row pass, mixed layout [x][P]
+    const cf *Zbase;      // vort_c0 (layout above)
+    cf *Zcur, *Acc, *Zout;
+    cf *W4;               // four derivative fields, mixed layout, field f at W4 + f*fstride
+    long fstride;
+    int P;                // pitch of the mixed arrays
+    int ntiles;           // (ny/2)/8
+    int stage;            // 0..3
+    float nu, dt;
+    SpecCoef coef;
+    const cf *tw256;      // W256^m, m < 256
+    const cf *tw4096;     // W4096^m (first 256 entries used)
+};
+
+// 16x16 transpose between the wave index and the register index (one column = 8 B per lane)
+FB_DEV void cf_xchg_waves(cf *lds, cf *v, int w, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[(r * 16 + w) * 64 + lane] = v[r];
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = lds[(w * 16 + r) * 64 + lane];
+    lds_barrier();
+}
+
+// 16x16 transpose between l = lane>>2 and the register index, inside each wave's own LDS region
+FB_DEV void cf_xchg_lanes(cf *lds, cf *v, int w, int l, int c)
+{
+    cf *reg = lds + w * (16 * CF_X2_STR);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) reg[r * CF_X2_STR + l * 4 + c] = v[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-local: DS ops of a wave are in order
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = reg[l * CF_X2_STR + r * 4 + c];
+    lds_barrier();                                           // region is reused by the other waves next
+}
+
+// The two columns go through every step one after the other, fenced with sched_barrier: letting
+// the scheduler interleave two radix-16 butterflies needs far more than the 128 VGPRs a
+// 1024-thread workgroup has.
+#define CF_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// radix-16 butterfly with a scheduling fence after every radix-4 sub-butterfly: same arithmetic as
+// Bfly<16>, but the four independent sub-butterflies are not interleaved (a few temporaries
+// instead of four sets of them)
+template <int DIR> FB_DEV void cf_bfly16(cf *v)
+{
+    fft4<DIR>(v[0], v[4], v[8], v[12]);  CF_FENCE();
+    fft4<DIR>(v[1], v[5], v[9], v[13]);  CF_FENCE();
+    fft4<DIR>(v[2], v[6], v[10], v[14]); CF_FENCE();
+    fft4<DIR>(v[3], v[7], v[11], v[15]); CF_FENCE();
+    v[5]  = mul_w16<1, DIR>(v[5]);  v[6]  = mul_w16<2, DIR>(v[6]);  v[7]  = mul_w16<3, DIR>(v[7]);
+    v[9]  = mul_w16<2, DIR>(v[9]);  v[10] = mul_w16<4, DIR>(v[10]); v[11] = mul_w16<6, DIR>(v[11]);
+    v[13] = mul_w16<3, DIR>(v[13]); v[14] = mul_w16<6, DIR>(v[14]); v[15] = mul_w16<9, DIR>(v[15]);
+    CF_FENCE();
+    fft4<DIR>(v[0], v[1], v[2], v[3]);     CF_FENCE();
+    fft4<DIR>(v[4], v[5], v[6], v[7]);     CF_FENCE();
+    fft4<DIR>(v[8], v[9], v[10], v[11]);   CF_FENCE();
+    fft4<DIR>(v[12], v[13], v[14], v[15]); CF_FENCE();
+    cf t;
+    t = v[1];  v[1]  = v[4];  v[4]  = t;
+    t = v[2];  v[2]  = v[8];  v[8]  = t;
+    t = v[3];  v[3]  = v[12]; v[12] = t;
+    t = v[6];  v[6]  = v[9];  v[9]  = t;
+    t = v[7];  v[7]  = v[13]; v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
+template <int DIR>
+FB_DEV void cf_fft4096(cf *lds, const cf *tabA, const cf *tabB, cf (*v)[16], int w, int l, int c, int lane)
+{
+    if (DIR < 0) {
+        // mixed -> spectral
+#pragma unroll
+        for (int col = 0; col < 2; ++col) {
+            cf_bfly16<-1>(v[col]);                                       // over i -> k1
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) { v[col][k1] = cmul(v[col][k1], tabB[w * k1]); if ((k1 & 3) == 3) CF_FENCE(); }
+            cf_xchg_waves(lds, v[col], w, lane);                             // now wave = k1, reg = w
+            CF_FENCE();
+        }
+        const cf a = tabA[l * w];                                            // W4096^{l k1}
+#pragma unroll
+        for (int col = 0; col < 2; ++col) {
+            cf_bfly16<-1>(v[col]);                                       // over w -> k2
+            v[col][0] = cmul(v[col][0], a);
+#pragma unroll
+            for (int k2 = 1; k2 < 16; ++k2) { v[col][k2] = cmul(v[col][k2], cmul(a, tabB[l * k2])); if ((k2 & 3) == 3) CF_FENCE(); }
+            cf_xchg_lanes(lds, v[col], w, l, c);                             // now l = k2, reg = l
+            CF_FENCE();
+        }
+#pragma unroll
+        for (int col = 0; col < 2; ++col) { cf_bfly16<-1>(v[col]); CF_FENCE(); }   // over l -> k3
+    } else {
+        // spectral -> mixed (thread: k1 = w, k2 = l, reg = k3)
+#pragma unroll
+        for (int col = 0; col < 2; ++col) {
+            cf_bfly16<+1>(v[col]);                                       // over k3 -> l (in reg)
+#pragma unroll
+            for (int lr = 1; lr < 16; ++lr) { v[col][lr] = cmulc(v[col][lr], cmul(tabA[lr * w], tabB[lr * l])); if ((lr & 3) == 3) CF_FENCE(); }
+            cf_xchg_lanes(lds, v[col], w, l, c);                             // now lane-l = l, reg = k2
+            CF_FENCE();
+        }
+#pragma unroll
+        for (int col = 0; col < 2; ++col) {
+            cf_bfly16<+1>(v[col]);                                       // over k2 -> w (in reg)
+#pragma unroll
+            for (int wr = 1; wr < 16; ++wr) { v[col][wr] = cmulc(v[col][wr], tabB[wr * w]); if ((wr & 3) == 3) CF_FENCE(); }
+            cf_xchg_waves(lds, v[col], w, lane);                             // now wave = w, reg = k1
+            CF_FENCE();
+        }
+#pragma unroll
+        for (int col = 0; col < 2; ++col) { cf_bfly16<+1>(v[col]); CF_FENCE(); }   // over k1 -> i
+    }
+}
+
+// Global accesses are written as (wave-uniform base pointer) + (32-bit per-lane byte offset): the
+// compiler then uses the SGPR-base addressing form and one offset VGPR serves all 16 rows, instead
+// of sixteen 64-bit per-lane addresses.
+FB_DEV float4 cf_ld4(const void *ubase, unsigned voff) { return *reinterpret_cast<const float4 *>(static_cast<const char *>(ubase) + voff); }
+FB_DEV void cf_st4(void *ubase, unsigned voff, float4 x) { *reinterpret_cast<float4 *>(static_cast<char *>(ubase) + voff) = x; }
+
+template <int STAGE>
+__global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *lds = reinterpret_cast<cf *>(smem_raw);
+    cf *tabB = lds + CF_X2_CF, *tabA = tabB + 256;
+    const int tid = threadIdx.x, lane = tid & 63, l = lane >> 2, c = lane & 3;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave id, in an SGPR
+    if (tid < 256) { tabB[tid] = a.tw256[tid]; tabA[tid] = a.tw4096[tid]; }
+
+    // adjacent tiles on one XCD (blocks b and b+8 share an XCD: MI355X_MICROARCH.md, dispatch)
+    int tile = blockIdx.x;
+    if ((a.ntiles & 7) == 0) tile = (blockIdx.x & 7) * (a.ntiles >> 3) + (blockIdx.x >> 3);
+    if (tile >= a.ntiles) return;
+
+    const int ky0 = tile * 8 + 2 * c;                                   // this thread's two columns: ky0, ky0+1
+    const unsigned voff_m = (unsigned)((l * a.P + 2 * c) * (int)sizeof(cf));            // mixed arrays: row l of the wave's 16, column pair c
+    const size_t ubase_m = ((size_t)(16 * w) * a.P + (size_t)tile * 8) * sizeof(cf);    // uniform part: rows 16 w.., tile's first column
+    const size_t rstep = (size_t)256 * a.P * sizeof(cf);                                // 256 rows, bytes
+    const unsigned voff_s = (unsigned)(lane * (int)sizeof(float4));                     // state arrays: [tile][k3][thread]
+    const size_t ubase_s = (((size_t)tile * 16) * CF_THREADS + (size_t)w * 64) * sizeof(float4);
+    const size_t sstep = (size_t)CF_THREADS * sizeof(float4);
+
+    cf v[2][16];
+    {   // ---- tendency tile -> registers (rows 256 i + 16 w + l)
+        const char *src = reinterpret_cast<const char *>(a.Tin) + ubase_m;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 t = cf_ld4(src + i * rstep, voff_m);
+            v[0][i] = cf_make(t.x, t.y); v[1][i] = cf_make(t.z, t.w);
+        }
+    }
+    __syncthreads();                                            // twiddle tables are in LDS
+    cf_fft4096<-1>(lds, tabA, tabB, v, w, l, c, lane);           // main.cpp:237 (x part)
+
+    // ---- viscous term, mask, RK stage update: kx = w + 16 l + 256 k3   (main.cpp:148,240-251,296-312)
+    const char *Z0 = reinterpret_cast<const char *>(a.Zbase) + ubase_s;
+    char *ZC = reinterpret_cast<char *>(a.Zcur) + ubase_s, *AC = reinterpret_cast<char *>(a.Acc) + ubase_s,
+         *ZO = reinterpret_cast<char *>(a.Zout) + ubase_s;
+    const double ky2a = a.coef.ky2[ky0], ky2b = a.coef.ky2[ky0 + 1];
+    const float gya = a.coef.gy[ky0], gyb = a.coef.gy[ky0 + 1];
+    const unsigned voff_kx = (unsigned)(16 * l);                 // kx = (w + 256 k3) [uniform] + 16 l
+    constexpr int stage = STAGE;
+    const float nu = a.nu, dt = a.dt, hdt = (stage == 2) ? a.dt : a.dt / 2.0f;
+#pragma unroll
+    for (int k3 = 0; k3 < 16; ++k3) {
+        const int ikx = w + 256 * k3 + 16 * l;
+        const double kx2 = (a.coef.kx2 + (w + 256 * k3))[voff_kx];
+        const float lapa = (float)(-(kx2 + ky2a)), lapb = (float)(-(kx2 + ky2b));
+        const float mska = coef_mask(a.coef, ikx, ky0), mskb = coef_mask(a.coef, ikx, ky0 + 1);
+        const float4 z0 = cf_ld4(Z0 + k3 * sstep, voff_s);
+        const float4 zc = stage == 0 ? z0 : cf_ld4(ZC + k3 * sstep, voff_s);
+        float4 k;
+        k.x = (v[0][k3].x + (zc.x * lapa) * nu) * mska; k.y = (v[0][k3].y + (zc.y * lapa) * nu) * mska;
+        k.z = (v[1][k3].x + (zc.z * lapb) * nu) * mskb; k.w = (v[1][k3].y + (zc.w * lapb) * nu) * mskb;
+        float4 acc, zn;
+        if (stage == 0) {
+            acc = k;
+            zn = make_float4(z0.x + k.x * hdt, z0.y + k.y * hdt, z0.z + k.z * hdt, z0.w + k.w * hdt);
+        } else if (stage < 3) {
+            const float4 ac = cf_ld4(AC + k3 * sstep, voff_s);
+            acc = make_float4(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y, ac.z + 2.0f * k.z, ac.w + 2.0f * k.w);
+            zn = make_float4(z0.x + k.x * hdt, z0.y + k.y * hdt, z0.z + k.z * hdt, z0.w + k.w * hdt);
+        } else {
+            const float4 ac = cf_ld4(AC + k3 * sstep, voff_s);
+            acc = ac;
+            zn = make_float4(z0.x + (ac.x + k.x) * dt / 6.0f, z0.y + (ac.y + k.y) * dt / 6.0f,
+                             z0.z + (ac.z + k.z) * dt / 6.0f, z0.w + (ac.w + k.w) * dt / 6.0f);
+        }
+        if (stage < 3) { cf_st4(AC + k3 * sstep, voff_s, acc); cf_st4(ZC + k3 * sstep, voff_s, zn); }
+        else cf_st4(ZO + k3 * sstep, voff_s, zn);
+        v[0][k3] = cf_make(zn.x, zn.y); v[1][k3] = cf_make(zn.z, zn.w);
+        if ((k3 & 1) == 1) CF_FENCE();
+    }
+
+    // ---- four derivatives of the new state, each transformed back and stored (fftwfop.cpp:87-117)
+    const char *ZN = stage < 3 ? ZC : ZO;
+#pragma unroll 1
+    for (int f = 0; f < 4; ++f) {
+        if (f > 0) {                                  // registers were consumed: fetch the state again (own writes, L2/MALL)
+            const unsigned vs = (unsigned)launder((int)voff_s);
+#pragma unroll
+            for (int k3 = 0; k3 < 16; ++k3) {
+                const float4 z = cf_ld4(ZN + k3 * sstep, vs);
+                v[0][k3] = cf_make(z.x, z.y); v[1][k3] = cf_make(z.z, z.w);
+            }
+        }
+        const bool psi = f >= 2, use_gx = (f == 0 || f == 3);
+        const unsigned vkx = (unsigned)launder((int)voff_kx);     // per-iteration copy: keeps the coefficient loads inside the loop
+#pragma unroll
+        for (int k3 = 0; k3 < 16; ++k3) {
+            cf za = v[0][k3], zb = v[1][k3];
+            if (psi) {                                // psi_c = invertLaplacian(vort_c)   main.cpp:179
+                const double kx2 = (a.coef.kx2 + (w + 256 * k3))[vkx];
+                const float lia = (w + 256 * k3 + 16 * l == 0 && ky0 == 0) ? 1.0f : (float)(-(kx2 + ky2a));
+                const float lib = (float)(-(kx2 + ky2b));
+                za = cf_make(za.x / lia, za.y / lia); zb = cf_make(zb.x / lib, zb.y / lib);
+            }
+            const float gx = (a.coef.gx + (w + 256 * k3))[vkx];
+            const float ka = use_gx ? gx : gya, kb = use_gx ? gx : gyb;
+            v[0][k3] = cf_make(-za.y * ka, za.x * ka);
+            v[1][k3] = cf_make(-zb.y * kb, zb.x * kb);
+            CF_FENCE();
+        }
+        cf_fft4096<+1>(lds, tabA, tabB, v, w, l, c, lane);
+        char *dst = reinterpret_cast<char *>(a.W4) + (size_t)f * a.fstride * sizeof(cf) + ubase_m;
+        const unsigned vm = (unsigned)launder((int)voff_m);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            cf_st4(dst + i * rstep, vm, make_float4(v[0][i].x, v[0][i].y, v[1][i].x, v[1][i].y));
+    }
+}
+
+// ---- layout conversion: 3-pass private spectral layout (row N2*c+d, pitch P) <-> this kernel's
+template <bool TO_FULL>
+__global__ void __launch_bounds__(256) k_full_relayout(const cf *__restrict__ in, cf *__restrict__ out, int P, int N1, int N2, int ntiles)
+{
+    // one thread per (tile, k3, tid, col)
+    const size_t total = (size_t)ntiles * 16 * CF_THREADS * 2;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(idx & 1);
+        const int tid = (int)((idx >> 1) & (CF_THREADS - 1));
+        const int k3 = (int)((idx >> 11) & 15);
+        const int tile = (int)(idx >> 15);
+        const int w = tid >> 6, l = (tid >> 2) & 15, c = tid & 3;
+        const int kx = w + 16 * l + 256 * k3, ky = tile * 8 + 2 * c + col;
+        const int cc = kx % N1, d = kx / N1;                       // 3-pass layout: row N2*cc + d holds kx = cc + N1*d
+        const size_t p3 = (size_t)(N2 * cc + d) * P + ky;
+        if (TO_FULL) out[idx] = in[p3]; else out[p3] = in[idx];
+    }
+}

@@ -10,6 +10,7 @@
 
 #include "../../include/fftbaro.h"
 #include "fb_kernels.h"
+#include "fb_col_full.h"
 
 // --------------------------------------------------------------------------------------------
 // errors
@@ -57,7 +58,8 @@ struct fb_ctx {
     hipStream_t stream;
     // device tables
     float *d_gx; double *d_kx2; float *d_gy; double *d_ky2; double gws;
-    cf *d_tw_n1, *d_tw_n2, *d_tw_big, *d_tw_row_bwd, *d_tw_row_fwd;
+    cf *d_tw_n1, *d_tw_n2, *d_tw_big, *d_tw_row_bwd, *d_tw_row_fwd, *d_tw_256;
+    bool nyq_frozen;            // the ky = ny/2 column lies outside the dealiasing circle (always on square grids)
     cf *d_scratch;              // nx*P complex, lazily allocated (standalone r2c / c2r)
     // host copies of the 1-D tables (fb_get_tables)
     std::vector<float> h_gx, h_gy; std::vector<double> h_kx2, h_ky2;
@@ -180,11 +182,12 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
     const int dxw = (int)ceil(((double)(float)nx) / 3.0), dyw = (int)ceil(((double)(float)ny) / 3.0);   // :11-12
     c->gws = (double)(float)((double)dxw * dxw + (double)dyw * dyw);              // :57
 
+    c->nyq_frozen = ((double)(ny / 2) * (double)(ny / 2) >= c->gws);
     int rc;
     if ((rc = upload(&c->d_gx, c->h_gx)) || (rc = upload(&c->d_kx2, c->h_kx2)) ||
         (rc = upload(&c->d_gy, c->h_gy)) || (rc = upload(&c->d_ky2, c->h_ky2)) ||
         (rc = upload(&c->d_tw_n1, make_root_table(c->N1))) || (rc = upload(&c->d_tw_n2, make_root_table(c->N2))) ||
-        (rc = upload(&c->d_tw_big, make_root_table(nx))) ||
+        (rc = upload(&c->d_tw_big, make_root_table(nx))) || (rc = upload(&c->d_tw_256, make_root_table(256))) ||
         (rc = upload(&c->d_tw_row_bwd, make_row_table(ny, plan_radices_rt(ny, false)))) ||
         (rc = upload(&c->d_tw_row_fwd, make_row_table(ny, plan_radices_rt(ny, true))))) {
         delete c; return rc;
@@ -202,7 +205,7 @@ extern "C" int fb_destroy(fb_ctx *c)
 {
     if (!c) return FB_OK;
     hipFree(c->d_gx); hipFree(c->d_kx2); hipFree(c->d_gy); hipFree(c->d_ky2);
-    hipFree(c->d_tw_n1); hipFree(c->d_tw_n2); hipFree(c->d_tw_big); hipFree(c->d_tw_row_bwd); hipFree(c->d_tw_row_fwd);
+    hipFree(c->d_tw_n1); hipFree(c->d_tw_n2); hipFree(c->d_tw_big); hipFree(c->d_tw_row_bwd); hipFree(c->d_tw_row_fwd); hipFree(c->d_tw_256);
     if (c->d_scratch) hipFree(c->d_scratch);
     delete c;
     return FB_OK;
@@ -514,6 +517,10 @@ struct fb_model {
     // world == 1: w4_recv == w4_send == W4 and t_send == t_recv == TT (no exchange)
     cf *w4_send, *w4_recv, *t_send, *t_recv;
     bool own_buffers;
+    // single-pass x-transform path (fb_col_full.h): ZA/ZB/ACC then use that kernel's private layout and
+    // the frozen ky = ny/2 column of vort_c is kept in znyq[nx] (natural kx order)
+    bool full;
+    cf *znyq;
     float *src;                      // vort_src or NULL (== zeros)
     cf *nat[3];                      // natural-layout temporaries for the record path (lazy)
     bool primed;                     // W4 holds the block-backward derivatives of ZA
@@ -526,6 +533,19 @@ static int model_create_impl(fb_model **out, fb_ctx *c, float nu, float dt, bool
     fb_model *m = new fb_model();
     memset(m, 0, sizeof(*m));
     m->c = c; m->nu = nu; m->dt = dt; m->own_buffers = own;
+    m->full = own && c->world == 1 && c->nx == 4096 && c->nyq_frozen && ((c->ny / 2) % 8) == 0 && getenv("FB_FULL_PASS") &&
+              getenv("FB_FULL_PASS")[0] == '1';      // experimental, off by default: measured slower
+    if (m->full) {
+        if (hipMalloc((void **)&m->znyq, (size_t)c->nx * sizeof(cf)) != hipSuccess) { delete m; return fail(FB_ENOMEM, "model allocation failed"); }
+        static bool attr = false;
+        if (!attr) {
+            HIPCHK(hipFuncSetAttribute((const void *)k_col_full<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS_BYTES));
+            HIPCHK(hipFuncSetAttribute((const void *)k_col_full<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS_BYTES));
+            HIPCHK(hipFuncSetAttribute((const void *)k_col_full<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS_BYTES));
+            HIPCHK(hipFuncSetAttribute((const void *)k_col_full<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS_BYTES));
+            attr = true;
+        }
+    }
     const size_t n = priv_elems(c) * sizeof(cf);
     cf **arr[] = {&m->ZA, &m->ZB, &m->ACC};
     for (auto p : arr) {
@@ -576,6 +596,7 @@ extern "C" int fb_model_destroy(fb_model *m)
 {
     if (!m) return FB_OK;
     hipFree(m->ZA); hipFree(m->ZB); hipFree(m->ACC);
+    if (m->znyq) hipFree(m->znyq);
     if (m->own_buffers) { hipFree(m->TT); hipFree(m->W4); }
     if (m->src) hipFree(m->src);
     for (auto p : m->nat) if (p) hipFree(p);
@@ -592,14 +613,21 @@ extern "C" int fb_model_info(fb_model *m, size_t *hbm, size_t *alg)
     return FB_OK;
 }
 
+static MidArgs mid_args(fb_model *m, int stage);
+static int full_import_state(fb_model *m, cf *spec3);
+static int full_export_state(fb_model *m, cf *dst);
+
 extern "C" int fb_model_set_vort(fb_model *m, const float *d_vort)
 {
     if (!m || !d_vort) return fail(FB_EINVAL, "fb_model_set_vort: NULL");
     fb_ctx *c = m->c;
     NEED_SINGLE(c);
-    HIPCHK(hipMemsetAsync(m->ZA, 0, priv_elems(c) * sizeof(cf), c->stream));
+    cf *dst = m->full ? m->ZB : m->ZA;                      // full path: via the 3-pass layout in ZB (stage scratch)
+    HIPCHK(hipMemsetAsync(dst, 0, priv_elems(c) * sizeof(cf), c->stream));
     m->primed = false;
-    return r2c_private(c, d_vort, m->ZA);                   // main.cpp:256
+    int rc = r2c_private(c, d_vort, dst);                   // main.cpp:256
+    if (rc || !m->full) return rc;
+    return full_import_state(m, dst);
 }
 
 extern "C" int fb_model_set_source(fb_model *m, const float *d_src)
@@ -623,6 +651,65 @@ static MidArgs mid_args(fb_model *m, int stage)
     return a;
 }
 
+
+// copy the ky = col column of a 3-pass-layout spectral array to / from znyq[kx]
+template <bool EXTRACT>
+__global__ void k_nyq_col(cf *arr, cf *znyq, int nx, int P, int N1, int N2, int col)
+{
+    const int kx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kx >= nx) return;
+    const size_t p = (size_t)(N2 * (kx % N1) + kx / N1) * P + col;
+    if (EXTRACT) znyq[kx] = arr[p]; else arr[p] = znyq[kx];
+}
+
+// full-path model: vort_c arrives in the 3-pass layout in `spec3` (clobbered): prime W4 through the
+// 3-pass kernels (all columns, including the frozen ky = ny/2 one), then move the state over
+static int full_import_state(fb_model *m, cf *spec3)
+{
+    fb_ctx *c = m->c;
+    int rc;
+    MidArgs a = mid_args(m, -1);
+    a.Zbase = spec3;
+    if ((rc = launch_col_mid(c, a))) return rc;
+    if ((rc = launch_col_strided<+1>(c, m->W4, 4, (long)priv_elems(c)))) return rc;
+    hipLaunchKernelGGL((k_nyq_col<true>), dim3((c->nx + 255) / 256), dim3(256), 0, c->stream, spec3, m->znyq, c->nx, c->P, c->N1, c->N2, c->ny / 2);
+    const int ntiles = (c->ny / 2) / 8;
+    hipLaunchKernelGGL((k_full_relayout<true>), dim3(c->max_wg), dim3(256), 0, c->stream, (const cf *)spec3, m->ZA, c->P, c->N1, c->N2, ntiles);
+    HIPCHK(hipGetLastError());
+    m->primed = true;
+    return FB_OK;
+}
+
+// full-path model: vort_c -> 3-pass layout in `dst` (nx*P complex; pad columns zeroed)
+static int full_export_state(fb_model *m, cf *dst)
+{
+    fb_ctx *c = m->c;
+    HIPCHK(hipMemsetAsync(dst, 0, priv_elems(c) * sizeof(cf), c->stream));
+    const int ntiles = (c->ny / 2) / 8;
+    hipLaunchKernelGGL((k_full_relayout<false>), dim3(c->max_wg), dim3(256), 0, c->stream, (const cf *)m->ZA, dst, c->P, c->N1, c->N2, ntiles);
+    hipLaunchKernelGGL((k_nyq_col<false>), dim3((c->nx + 255) / 256), dim3(256), 0, c->stream, dst, m->znyq, c->nx, c->P, c->N1, c->N2, c->ny / 2);
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
+static int launch_col_full(fb_model *m, int stage)
+{
+    fb_ctx *c = m->c;
+    FullArgs a;
+    a.Tin = m->t_recv; a.Zbase = m->ZA; a.Zcur = m->ZB; a.Acc = m->ACC; a.Zout = m->ZA; a.W4 = m->w4_send;
+    a.fstride = (long)priv_elems(c); a.P = c->P; a.ntiles = (c->ny / 2) / 8; a.stage = stage; a.nu = m->nu; a.dt = m->dt;
+    a.coef = make_coef(c); a.tw256 = c->d_tw_256; a.tw4096 = c->d_tw_big;
+    const dim3 g(a.ntiles), b(CF_THREADS);
+    switch (stage) {
+    case 0: hipLaunchKernelGGL(k_col_full<0>, g, b, CF_LDS_BYTES, c->stream, a); break;
+    case 1: hipLaunchKernelGGL(k_col_full<1>, g, b, CF_LDS_BYTES, c->stream, a); break;
+    case 2: hipLaunchKernelGGL(k_col_full<2>, g, b, CF_LDS_BYTES, c->stream, a); break;
+    default: hipLaunchKernelGGL(k_col_full<3>, g, b, CF_LDS_BYTES, c->stream, a); break;
+    }
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
 // optional per-launch HIP-event profiler (bench.py's roofline leg)
 struct StepProf {
     std::vector<hipEvent_t> ev0[4], ev1[4];
@@ -641,6 +728,7 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
     if (c->world != 1) return fail(FB_EINVAL, "fb_model_step on a slab model: drive it with fb_model_phase + all-to-all");
     int rc;
     if (nsteps == 0) return FB_OK;
+    if (m->full && !m->primed) return fail(FB_EINVAL, "fb_model_step: set the state first");
     if (!m->primed) {
         if ((rc = launch_col_mid(c, mid_args(m, -1)))) return rc;
         m->primed = true;
@@ -648,6 +736,17 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
     const float scale = 1.0f / (float)((size_t)c->nx * c->ny);
     for (int s = 0; s < nsteps; ++s) {
         for (int k = 0; k < 4; ++k) {
+            if (m->full) {                        // two launches per stage: row pass, single-pass x transform
+                RowArgs a = row_args_base(c);
+                a.M = m->w4_recv; a.m_fstride = (long)priv_elems(c); a.T = m->t_send; a.src = m->src; a.scale = scale;
+                PROF_BEGIN(1);
+                if ((rc = launch_row<ROW_FUSED>(c, a))) return rc;
+                PROF_END(1);
+                PROF_BEGIN(3);
+                if ((rc = launch_col_full(m, k))) return rc;
+                PROF_END(3);
+                continue;
+            }
             PROF_BEGIN(0);
             if ((rc = launch_col_strided<+1>(c, m->w4_send, 4, (long)priv_elems(c)))) return rc;
             PROF_END(0);
@@ -754,6 +853,11 @@ extern "C" int fb_model_get_spectrum(fb_model *m, float *d_spec)
 {
     if (!m || !d_spec) return fail(FB_EINVAL, "fb_model_get_spectrum: NULL");
     NEED_SINGLE(m->c);
+    if (m->full) {
+        int rc;
+        if ((rc = ensure_scratch(m->c)) || (rc = full_export_state(m, m->c->d_scratch))) return rc;
+        return relayout(m->c, m->c->d_scratch, (cf *)d_spec, false);
+    }
     return relayout(m->c, m->ZA, (cf *)d_spec, false);
 }
 
@@ -762,6 +866,10 @@ extern "C" int fb_model_set_spectrum(fb_model *m, const float *d_spec)
     if (!m || !d_spec) return fail(FB_EINVAL, "fb_model_set_spectrum: NULL");
     NEED_SINGLE(m->c);
     m->primed = false;
+    if (m->full) {
+        int rc = relayout(m->c, (const cf *)d_spec, m->ZB, true);
+        return rc ? rc : full_import_state(m, m->ZB);
+    }
     return relayout(m->c, (const cf *)d_spec, m->ZA, true);
 }
 
@@ -773,7 +881,8 @@ extern "C" int fb_model_get_vort(fb_model *m, float *d_vort)
     int rc;
     if ((rc = ensure_scratch(c))) return rc;
     // copy of vort_c (main.cpp:273), c2r, normalise (main.cpp:275)
-    HIPCHK(hipMemcpyAsync(c->d_scratch, m->ZA, priv_elems(c) * sizeof(cf), hipMemcpyDeviceToDevice, c->stream));
+    if (m->full) { if ((rc = full_export_state(m, c->d_scratch))) return rc; }
+    else HIPCHK(hipMemcpyAsync(c->d_scratch, m->ZA, priv_elems(c) * sizeof(cf), hipMemcpyDeviceToDevice, c->stream));
     return c2r_private(c, c->d_scratch, d_vort, 1.0f / (float)((size_t)c->nx * c->ny));
 }
 
