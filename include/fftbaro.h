@@ -142,14 +142,15 @@ int fb_model_profile_steps(fb_model *m, int nsteps, float *ms_sum, int *launches
  * field and the ky columns [ky0, ky0+KS) of every spectral field (KS = 16*ceil((ny/2+1)/(16*world))).
  * The engine does the local passes; the CALLER does the two all-to-all transposes per RK stage
  * (RCCL via torch.distributed, or ncclSend/ncclRecv) on four buffers it owns, E = nx*KS complex:
- *   w4_send [4][nx][KS]          column-slab layout: written by FB_PH_PRIME / FB_PH_COL_FWD,
- *                                 finished by FB_PH_COL_BWD; destination d's block of field f is the
- *                                 contiguous range [f][d*XL .. (d+1)*XL)[KS]
- *   w4_recv [4][world][XL][KS]   row-slab layout: block s of field f comes from rank s
+ *   w4_send [world][4][XL][KS]   destination-blocked: block d = rows d*XL..(d+1)*XL of the four fields,
+ *                                 written by FB_PH_PRIME / FB_PH_COL_FWD, finished by FB_PH_COL_BWD
+ *   w4_recv [world][4][XL][KS]   block s comes from rank s (its ky slab of this rank's rows)
  *   t_send  [world][XL][KS]      written by FB_PH_ROW / FB_PH_R2C_ROWS; block d goes to rank d
  *   t_recv  [nx][KS]             block s (rows s*XL..) comes from rank s
- * One RK4 step = for stage in 0..3 { COL_BWD; all-to-all(w4, per field); ROW; all-to-all(t); COL_FWD(stage) },
- * preceded once by PRIME after the state was set.
+ * so each transpose is ONE equal-split all-to-all of a contiguous buffer (4E and E complex).
+ * One RK4 step = for stage in 0..3 { COL_BWD; all-to-all(w4); ROW; all-to-all(t); COL_FWD(stage) },
+ * preceded once by PRIME after the state was set.  The record path (C2R_*) runs the transposes in
+ * the opposite roles: C2R_COLS leaves [dst][XL][KS] in t_recv, all-to-all(t_recv -> t_send), C2R_ROWS.
  * ------------------------------------------------------------------------------------- */
 int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, int rank, int world);
 int fb_slab_geometry(fb_ctx *ctx, int *rows_local, int *cols_per_slab, int *ky0, size_t *elems_per_field);
@@ -161,8 +162,8 @@ int fb_model_create_slab(fb_model **out, fb_ctx *ctx, float nu, float dt, float 
 #define FB_PH_COL_FWD   3   /* t_recv -> forward x pass, viscosity, mask, RK stage `stage`, derivatives    */
 #define FB_PH_R2C_ROWS  4   /* d_real_in (local rows [XL][ny]) -> t_send           (set_vort, first half)  */
 #define FB_PH_R2C_COLS  5   /* t_recv -> vort_c                                    (set_vort, second half) */
-#define FB_PH_C2R_COLS  6   /* copy of vort_c -> w4_send field 0                   (get_vort, first half)  */
-#define FB_PH_C2R_ROWS  7   /* w4_recv field 0 -> d_real_out (local rows, normalised)                      */
+#define FB_PH_C2R_COLS  6   /* copy of vort_c -> x-backward-transformed columns in t_recv (get_vort, 1st half) */
+#define FB_PH_C2R_ROWS  7   /* t_send ([src][XL][KS]) -> d_real_out (local rows, normalised)                  */
 int fb_model_phase(fb_model *m, int phase, int stage, const float *d_real_in, float *d_real_out);
 
 /* ---------------------------------------------------------------------------------------

@@ -43,13 +43,13 @@ class NumpyBackend:
         d = np.stack([self.ikx * z, self.iky * z, self.iky * psi, self.ikx * psi])     # main.cpp:151,165,198,212
         return d
 
-    def _put_w4_cols(self, fields_spec):
-        cols = np.fft.ifft(fields_spec, axis=1) * self.nx                               # backward x pass, unnormalised
-        self.w4_send.view(-1)[:cols.size] = torch.from_numpy(np.ascontiguousarray(cols).reshape(-1))
-
     def _rows_from_w4(self, f):
-        blk = self.w4_recv.numpy()[f * self.E:(f + 1) * self.E].reshape(self.world, self.XL, self.KS)
+        blk = self.w4_recv.numpy().reshape(self.world, 4, self.XL, self.KS)[:, f]       # [src][XL][KS]
         return np.concatenate(list(blk), axis=1)[:, :self.hy]                            # [XL][hy]
+
+    def _rows_from_t_send(self):
+        blk = self.t_send.numpy().reshape(self.world, self.XL, self.KS)
+        return np.concatenate(list(blk), axis=1)[:, :self.hy]
 
     def _rows_to_t(self, rows_spec):
         ptot = self.KS * self.world
@@ -91,16 +91,17 @@ class NumpyBackend:
         elif ph == PH_R2C_COLS:
             self.Z = np.fft.fft(self.t_recv.numpy().reshape(nx, self.KS), axis=0)
         elif ph == PH_C2R_COLS:
-            cols = np.fft.ifft(self.Z, axis=0) * nx
-            self.w4_send.view(-1)[:cols.size] = torch.from_numpy(np.ascontiguousarray(cols).reshape(-1))
+            cols = np.fft.ifft(self.Z, axis=0) * nx                                      # [x][KS] == [dst][XL][KS]
+            self.t_recv.view(-1)[:] = torch.from_numpy(np.ascontiguousarray(cols).reshape(-1))
         elif ph == PH_C2R_ROWS:
-            real_out.copy_(torch.from_numpy(np.fft.irfft(self._rows_from_w4(0), n=ny, axis=1) * ny / (nx * ny)))
+            real_out.copy_(torch.from_numpy(np.fft.irfft(self._rows_from_t_send(), n=ny, axis=1) * ny / (nx * ny)))
         else:
             raise ValueError(ph)
 
     def _stash_block(self):
-        cols = np.fft.ifft(self.pending, axis=1) * self.nx
-        self.w4_send.view(-1)[:] = torch.from_numpy(np.ascontiguousarray(cols).reshape(-1))
+        cols = np.fft.ifft(self.pending, axis=1) * self.nx                               # [4][x][KS]
+        blocked = cols.reshape(4, self.world, self.XL, self.KS).transpose(1, 0, 2, 3)    # [dst][4][XL][KS]
+        self.w4_send.view(-1)[:] = torch.from_numpy(np.ascontiguousarray(blocked).reshape(-1))
 
     def to_device_real(self, a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))

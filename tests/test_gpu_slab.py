@@ -22,16 +22,18 @@ class _Group:
         self.E = self.be[0].FL              # tensor elements per field (float32 view)
         self.blk = self.E // world
 
-    def xw4(self, nf=4):
+    def xw4(self):
         if self.world == 1:
             return
-        for f in range(nf):
-            _emulated_all_to_all([b.w4_recv for b in self.be], [b.w4_send for b in self.be], self.world, self.blk, f * self.E)
+        _emulated_all_to_all([b.w4_recv for b in self.be], [b.w4_send for b in self.be], self.world, 4 * self.blk)
 
-    def xt(self):
+    def xt(self, reverse=False):
         if self.world == 1:
             return
-        _emulated_all_to_all([b.t_recv for b in self.be], [b.t_send for b in self.be], self.world, self.blk)
+        if reverse:
+            _emulated_all_to_all([b.t_send for b in self.be], [b.t_recv for b in self.be], self.world, self.blk)
+        else:
+            _emulated_all_to_all([b.t_recv for b in self.be], [b.t_send for b in self.be], self.world, self.blk)
 
     def ph(self, ph, **kw):
         for b in self.be:
@@ -69,7 +71,7 @@ def test_slab_phases_match_fused_path(world, n, steps):
             g.xt()
             g.ph(S.PH_COL_FWD, stage=k)
     g.ph(S.PH_C2R_COLS)
-    g.xw4(nf=1)
+    g.xt(reverse=True)
     rows = []
     for b in g.be:
         out = b.empty_real()

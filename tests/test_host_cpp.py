@@ -21,7 +21,7 @@ def test_host_programs_link():
     import xlab_fftbarotropic_amd as X
     X.build_lib()
     _build()
-    for exe in ("barotropic_main.out", "shim_check.out"):
+    for exe in ("barotropic_main.out", "shim_check.out", "invert_pres.out"):
         assert os.access(os.path.join(HOST, exe), os.X_OK)
 
 
@@ -125,3 +125,43 @@ def test_driver_fifo_source(tmp_path):
         if step == 8:
             m.set_source(None)
         m.step(1)
+
+
+@pytest.mark.gpu
+def test_invert_pres_against_oracle_pipeline(tmp_path):
+    """invert_pres.cpp:114-188 on the C ABI, driven exactly like test/02-test_invert_pressure: the
+    driver's ./log, rewritten psi -> pres, piped into invert_pres."""
+    import re
+    import oracle_py as O
+    import ref_numpy as R
+    _build()
+    n = 256
+    (tmp_path / "input").mkdir()
+    (tmp_path / "output").mkdir()
+    O.make_field("kuo2004", n).tofile(str(tmp_path / "input" / "initial_vorticity.bin"))
+    subprocess.check_call([os.path.join(HOST, "barotropic_main.out"), "--npts", str(n), "--steps", "101"], cwd=str(tmp_path),
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lines = []
+    for ln in (tmp_path / "log").read_text().split():                    # the perl one-liner of example.sh:15
+        mm = re.match(r"(.*/)psi(.*?\.bin)", ln)
+        if mm:
+            lines.append("%s=>%spres%s" % (ln, mm.group(1), mm.group(2)))
+    assert len(lines) == 2
+    res = subprocess.run([os.path.join(HOST, "invert_pres.out"), "--npts", str(n), "-x", "3", "-y", "5"], cwd=str(tmp_path),
+                         input="\n".join(lines) + "\n", stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, check=True)
+    assert res.stdout.strip().endswith("Program ends. Congrats!")
+    ops = O.Operators(n, n, 6e5, 6e5)
+    g = np.float32(n * n)
+    for step in (0, 100):
+        psi = np.fromfile(str(tmp_path / "output" / ("psi_step_%d.bin" % step)), dtype="<f4").reshape(n, n)
+        pc = O.r2c(psi)
+        c2 = lambda s: O.c2r(ops.dealiase(s), n) / g
+        ty = ops.grady(pc)
+        dx2, dy2, dxdy = c2(ops.gradx(ops.gradx(pc))), c2(ops.grady(ty)), c2(ops.gradx(ty))
+        curv = dx2 * dy2 - dxdy * dxdy
+        lp = O.r2c(curv).view(np.float32)
+        lp = (lp + lp) + ops.laplacian(pc).view(np.float32) * np.float32(1e-5)
+        pres = O.c2r(ops.invertLaplacian(lp.view(np.complex64)), n) / g
+        pres = pres - pres.ravel()[3 + n * 5]
+        got = np.fromfile(str(tmp_path / "output" / ("pres_step_%d.bin" % step)), dtype="<f4").reshape(n, n)
+        assert R.rel_l2(got, pres) < 1e-4, step          # two chained 2-D FFT round trips of an ill-scaled field

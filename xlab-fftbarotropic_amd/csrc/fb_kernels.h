@@ -362,9 +362,19 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
 // -------------------------------------------------------------------------------------------
 // column sub-passes on wave tiles (16 columns x n rows), 4 waves per workgroup
 // -------------------------------------------------------------------------------------------
+// Row r of field f of a (possibly destination-blocked) mixed-space array lives at
+//   data + (r >> xl_shift)*dstride + f*fstride + (r & xl_mask)*P
+// one GPU: xl_shift = 31 (one block), so this is data + f*fstride + r*P.  Slab mode: the four derivative
+// fields are laid out [dst rank][field][local row][KS] so that ONE all-to-all moves all of them.
+struct RowMap {
+    int xl_shift, xl_mask; long dstride;
+    FB_DEV size_t off(int r, int P) const { return (size_t)(r >> xl_shift) * dstride + (size_t)(r & xl_mask) * P; }
+};
+
 struct ColArgs {
-    cf *data;          // field f at data + f*fstride
+    cf *data;          // field f at data + f*fstride (+ row map)
     long fstride;
+    RowMap rm;
     int nfields;
     int P;             // pitch (complex)
     int N1, N2;        // nx = N1*N2
@@ -388,11 +398,11 @@ __global__ void __launch_bounds__(256) k_col_strided(ColArgs a)
         const int f = (int)(tile / ((long)a.N2 * ntc));
         const int rem = (int)(tile - (long)f * a.N2 * ntc);
         const int b = rem / ntc, ct = rem - b * ntc;
-        cf *base = a.data + (size_t)f * a.fstride + (size_t)b * a.P + ct * 16;
+        cf *base = a.data + (size_t)f * a.fstride + ct * 16;
         float4 in[W::NLA];
 #pragma unroll
         for (int m = 0; m < W::NLA; ++m)
-            in[m] = *reinterpret_cast<const float4 *>(base + (size_t)(g + 8 * m) * a.N2 * a.P + 2 * cp);
+            in[m] = *reinterpret_cast<const float4 *>(base + a.rm.off((g + 8 * m) * a.N2 + b, a.P) + 2 * cp);
         cf out[W::NLB];
         wave_fft_A2B<n, DIR>(in, out, lds, a.tw_n, lane);
         if (W::lb_active(lane)) {
@@ -401,7 +411,7 @@ __global__ void __launch_bounds__(256) k_col_strided(ColArgs a)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int k = h + 4 * s + W::R1 * q;
-                    base[(size_t)k * a.N2 * a.P + c] = out[s * 8 + q];
+                    base[a.rm.off(k * a.N2 + b, a.P) + c] = out[s * 8 + q];
                 }
         }
     }
@@ -474,8 +484,9 @@ struct MidArgs {
     cf *Zcur;            // vort_c of this stage; updated in place (stage 0: written only)
     cf *Acc;             // running rk1 + 2 rk2 + 2 rk3
     cf *Zout;            // stage 3: new vort_c is written here (== Zbase's buffer)
-    cf *W4;              // four derived fields, field f at W4 + f*fstride
+    cf *W4;              // four derived fields, field f at W4 + f*fstride (+ row map)
     long fstride;
+    RowMap rm;
     int P, N1, N2;
     int ky0;             // global ky of local column 0 (slab offset)
     int stage;           // 0..3 RK stage whose tendency arrives; -1 = derive only (prime the pipeline)
@@ -588,7 +599,7 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
             }
             float4 out[W::NLA];
             wave_fft_B2A<n, +1>(fld, out, lds, a.tw_n, lf);
-            cf *dst = a.W4 + (size_t)f * a.fstride + tbase;
+            cf *dst = a.W4 + (size_t)f * a.fstride + a.rm.off(cb * n, a.P) + ct * 16;      // a block of n rows never straddles a rank
 #pragma unroll
             for (int m = 0; m < W::NLA; ++m) {
                 const cf wb = a.tw_big[(gf + 8 * m) * cb];

@@ -79,6 +79,11 @@ static void split_nx(int nx, int &N1, int &N2)
     case 8192: N1 = 128; N2 = 64; break;
     default: N1 = 128; N2 = 128; break;   // 16384
     }
+    // tuning override: FB_SPLIT_N1=<8|16|32|64|128> (both factors must stay within 8..128)
+    if (const char *e = getenv("FB_SPLIT_N1")) {
+        const int n1 = atoi(e);
+        if (n1 >= 8 && n1 <= 128 && (n1 & (n1 - 1)) == 0 && nx % n1 == 0 && nx / n1 >= 8 && nx / n1 <= 128) { N1 = n1; N2 = nx / n1; }
+    }
 }
 
 static std::vector<cf> make_root_table(int n)
@@ -384,9 +389,19 @@ static int col_grid(const fb_ctx *c, long ntiles)
     return (int)(g ? g : 1);
 }
 
-template <int DIR> static int launch_col_strided(fb_ctx *c, cf *data, int nfields, long fstride)
+// natural rows (one block) or, for the 4-field exchange buffer of a slab model, [dst][field][XL][KS]
+static RowMap rowmap_natural() { RowMap r; r.xl_shift = 31; r.xl_mask = 0x7fffffff; r.dstride = 0; return r; }
+static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+static RowMap rowmap_w4(const fb_ctx *c)
 {
-    ColArgs a; a.data = data; a.fstride = fstride; a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
+    if (c->world == 1) return rowmap_natural();
+    RowMap r; r.xl_shift = ilog2(c->XL); r.xl_mask = c->XL - 1; r.dstride = 4L * c->XL * c->P; return r;
+}
+static long w4_fstride(const fb_ctx *c) { return c->world == 1 ? (long)c->nx * c->P : (long)c->XL * c->P; }
+
+template <int DIR> static int launch_col_strided(fb_ctx *c, cf *data, int nfields, long fstride, RowMap rm = rowmap_natural())
+{
+    ColArgs a; a.data = data; a.fstride = fstride; a.rm = rm; a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
     a.tw_n = c->d_tw_n1; a.tw_big = c->d_tw_big;
     const long ntiles = (long)nfields * c->N2 * (c->P / 16);
     const dim3 g(col_grid(c, ntiles)), b(256);
@@ -404,7 +419,7 @@ template <int DIR> static int launch_col_strided(fb_ctx *c, cf *data, int nfield
 
 template <int DIR> static int launch_col_block(fb_ctx *c, cf *data, int nfields, long fstride)
 {
-    ColArgs a; a.data = data; a.fstride = fstride; a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
+    ColArgs a; a.data = data; a.fstride = fstride; a.rm = rowmap_natural(); a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
     a.tw_n = c->d_tw_n2; a.tw_big = c->d_tw_big;
     const long ntiles = (long)nfields * c->N1 * (c->P / 16);
     const dim3 g(col_grid(c, ntiles)), b(256);
@@ -646,7 +661,7 @@ static MidArgs mid_args(fb_model *m, int stage)
     fb_ctx *c = m->c;
     MidArgs a;
     a.Tin = m->t_recv; a.Zbase = m->ZA; a.Zcur = m->ZB; a.Acc = m->ACC; a.Zout = m->ZA; a.W4 = m->w4_send;
-    a.fstride = (long)priv_elems(c); a.P = c->P; a.N1 = c->N1; a.N2 = c->N2; a.ky0 = c->ky0; a.stage = stage;
+    a.fstride = w4_fstride(c); a.rm = rowmap_w4(c); a.P = c->P; a.N1 = c->N1; a.N2 = c->N2; a.ky0 = c->ky0; a.stage = stage;
     a.nu = m->nu; a.dt = m->dt; a.coef = make_coef(c); a.tw_n = c->d_tw_n2; a.tw_big = c->d_tw_big;
     return a;
 }
@@ -782,10 +797,11 @@ extern "C" int fb_model_phase(fb_model *m, int phase, int stage, const float *d_
         m->primed = true;
         return launch_col_mid(c, mid_args(m, -1));
     case FB_PH_COL_BWD:                                     // strided backward sub-pass on the 4 fields (in w4_send)
-        return launch_col_strided<+1>(c, m->w4_send, 4, E);
+        return launch_col_strided<+1>(c, m->w4_send, 4, w4_fstride(c), rowmap_w4(c));
     case FB_PH_ROW: {                                       // w4_recv (row slabs) -> tendency rows in t_send
         RowArgs a = row_args_base(c);
-        a.M = m->w4_recv; a.m_fstride = E; a.T = m->t_send; a.src = m->src; a.scale = scale;
+        a.M = m->w4_recv; a.m_fstride = w4_fstride(c); a.T = m->t_send; a.src = m->src; a.scale = scale;
+        if (c->world > 1) a.m_sstride = 4L * c->XL * c->P;   // w4_recv: [src rank][field][XL][KS]
         return launch_row<ROW_FUSED>(c, a);
     }
     case FB_PH_COL_FWD:                                     // t_recv (column slab) -> forward x pass + RK update + derivatives
@@ -802,14 +818,16 @@ extern "C" int fb_model_phase(fb_model *m, int phase, int stage, const float *d_
         HIPCHK(hipMemcpyAsync(m->ZA, m->t_recv, E * sizeof(cf), hipMemcpyDeviceToDevice, c->stream));
         m->primed = false;
         return FB_OK;
-    case FB_PH_C2R_COLS:                                    // copy of vort_c -> x-inverse-transformed columns in w4_send[0]
-        HIPCHK(hipMemcpyAsync(m->w4_send, m->ZA, E * sizeof(cf), hipMemcpyDeviceToDevice, c->stream));
+    case FB_PH_C2R_COLS:                                    // copy of vort_c -> x-inverse-transformed columns in t_recv
         m->primed = false;                                  // w4_send is clobbered
-        if ((rc = launch_col_block<+1>(c, m->w4_send, 1, 0))) return rc;
-        return launch_col_strided<+1>(c, m->w4_send, 1, 0);
-    case FB_PH_C2R_ROWS: {                                  // w4_recv[0] (row slabs) -> normalised real rows
+        // vort_c is staged in t_recv's buffer-sized scratch (field 0 region is destination-blocked in slab mode)
+        HIPCHK(hipMemcpyAsync(m->t_recv, m->ZA, E * sizeof(cf), hipMemcpyDeviceToDevice, c->stream));
+        if ((rc = launch_col_block<+1>(c, m->t_recv, 1, 0))) return rc;
+        if ((rc = launch_col_strided<+1>(c, m->t_recv, 1, 0))) return rc;      // natural [x][KS] == [dst][XL][KS]
+        return FB_OK;
+    case FB_PH_C2R_ROWS: {                                  // t_send (row slabs [src][XL][KS]) -> normalised real rows
         if (!d_real_out) return fail(FB_EINVAL, "fb_model_phase: d_real_out NULL");
-        RowArgs a = row_args_base(c); a.M = m->w4_recv; a.m_fstride = E; a.rout = d_real_out; a.scale = scale;
+        RowArgs a = row_args_base(c); a.M = m->t_send; a.m_fstride = 0; a.rout = d_real_out; a.scale = scale;
         return launch_row<ROW_INV>(c, a);
     }
     }

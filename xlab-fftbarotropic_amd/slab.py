@@ -127,17 +127,19 @@ class SlabModel:
         self.primed = False
 
     # -- the two transposes -------------------------------------------------------------------
-    def _exchange_w4(self, nfields=4):
-        be = self.be
+    def _exchange_w4(self):
         if self.world == 1:
             return
-        for f in range(nfields):                 # field f: [nx][KS] == [dst][XL][KS] -> [src][XL][KS]
-            _all_to_all(self.dist, be.w4_recv[f * self.FL:(f + 1) * self.FL], be.w4_send[f * self.FL:(f + 1) * self.FL], self.world)
+        # [dst][4][XL][KS] -> [src][4][XL][KS]: one collective for the four fields
+        _all_to_all(self.dist, self.be.w4_recv, self.be.w4_send, self.world)
 
-    def _exchange_t(self):
+    def _exchange_t(self, reverse=False):
         if self.world == 1:
             return
-        _all_to_all(self.dist, self.be.t_recv, self.be.t_send, self.world)
+        if reverse:                              # record path: columns (t_recv) -> rows (t_send)
+            _all_to_all(self.dist, self.be.t_send, self.be.t_recv, self.world)
+        else:
+            _all_to_all(self.dist, self.be.t_recv, self.be.t_send, self.world)
 
     # -- state ------------------------------------------------------------------------------
     def set_vort_local(self, vort_rows):
@@ -157,7 +159,7 @@ class SlabModel:
         """This rank's rows of vort (record path, main.cpp:273-281)."""
         be = self.be
         be.phase(PH_C2R_COLS)
-        self._exchange_w4(nfields=1)
+        self._exchange_t(reverse=True)
         out = be.empty_real()
         be.phase(PH_C2R_ROWS, real_out=out)
         self.primed = False
