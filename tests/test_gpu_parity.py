@@ -171,8 +171,10 @@ def test_model_vs_oracle(X, O, R, n, kind, steps):
     assert np.array_equal(_bits(m2.vort().cpu().numpy()), _bits(m.vort().cpu().numpy()))
 
 
-def test_model_nonsquare(X, O, R):
-    nx, ny = 128, 256
+@pytest.mark.parametrize("nx,ny", [(128, 256), (256, 8192), (128, 16384), (8192, 128), (16384, 64), (2048, 512)])
+def test_model_nonsquare(X, O, R, nx, ny):
+    """Also the cheap way to exercise the long-row kernels (ny = 8192, 16384: LDS-DMA path / 1024-thread
+    groups) and the long-column kernels (nx = 8192, 16384: 128-row wave tiles) against the oracle."""
     rng = np.random.default_rng(3)
     v0 = (1e-3 * rng.standard_normal((nx, ny))).astype(np.float32)
     v0 = O.c2r(O.Operators(nx, ny, L, L).dealiase(O.r2c(v0)), ny) / np.float32(nx * ny)

@@ -225,7 +225,7 @@ template <> struct RowPlan<2048>  { static constexpr int S = 3; static constexpr
 template <> struct RowPlan<4096>  { static constexpr int S = 3; static constexpr int R[4] = {16, 16, 16, 1}; };
 template <> struct RowPlan<8192>  { static constexpr int S = 4; static constexpr int R[4] = {4, 8, 16, 16}; };
 template <> struct RowPlan<16384> { static constexpr int S = 4; static constexpr int R[4] = {8, 16, 16, 8}; };
-template <int N> struct RowRes { static constexpr bool value = N <= 4096; };   // twiddles register-resident
+template <int N> struct RowRes { static constexpr bool value = true; };   // last-stage twiddles in registers, middle stages in an LDS table
 
 // register order of a radix-R stage: reg[e], e = m*R + q  <->  position t + ord_i<R>(e) * (N/16)
 template <int R> constexpr int ord_i(int e) { return (e / R) + (16 / R) * (e % R); }

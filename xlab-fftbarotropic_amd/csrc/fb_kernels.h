@@ -137,7 +137,7 @@ template <int N> struct RowCfg {
     static constexpr int LSTR = N + N / 16;               // padded complex per group (exchange buffer)
     // LDS-DMA prefetch of the next phase's two half-spectrum rows (fused mode): groups must be
     // whole waves and buffer + staging must leave room for two workgroups per CU
-    static constexpr bool DMA = N >= 1024 && N <= 4096;
+    static constexpr bool DMA = N >= 1024 && N <= 8192;
     static constexpr int GSTR = LSTR + (DMA ? N : 0);     // complex per group incl. staging [A: N/2][B: N/2]
     static constexpr bool RES = RowRes<N>::value;
     static constexpr bool SHARE = RES && RowPlanSymmetric<N>::value;        // one twiddle set for both directions
