@@ -118,6 +118,7 @@ template <int n> struct WaveTile {
     static constexpr int NLB = NP * 8;        // complex per lane in LB
     static constexpr int NLA = n / 8;         // float4 per lane in LA
     static constexpr int LDS_CF = R1 * WT_PSTR;
+    static constexpr bool TM = R1 >= 4;       // state arrays in the tile-major layout (fb_kernels.h)
     static FB_DEV bool lb_active(int lane) { return R1 >= 4 || (lane >> 4) < R1; }
     // register-allocation target of the fused middle kernel (waves per SIMD)
     static constexpr int MID_MIN_WAVES = n >= 128 ? 1 : (n >= 64 ? 3 : 4);

@@ -110,6 +110,26 @@ __global__ void __launch_bounds__(256) k_spec_relayout(const cf *__restrict__ in
     }
 }
 
+// State arrays (vort_c0, stage state, RK accumulator) are touched by k_col_mid only, so they live
+// in that kernel's register order ("tile-major"): tile (cb, ct) = N2 rows x 16 columns is contiguous,
+//   complex index = ((tile*(NLB/2) + e/2)*64 + lane)*2 + (e & 1),   e = 8 s + q  <->  row d = h + 4 s + R1 q,
+// lane = 16 h + c.  One float4 per lane then carries two elements and every wave access is 1 KiB
+// contiguous.  Used when R1 = N2/8 >= 4; smaller blocks keep the row layout (all lanes would not be active).
+template <bool TO_TM>
+__global__ void __launch_bounds__(256) k_state_relayout(const cf *__restrict__ in, cf *__restrict__ out, int nx, int P, int N2)
+{
+    const int R1 = N2 >> 3, NLB = N2 >> 2, ntc = P >> 4;
+    const size_t total = (size_t)nx * P;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / P), col = (int)(idx - (size_t)row * P);
+        const int cb = row / N2, d = row - cb * N2, ct = col >> 4, c = col & 15;
+        const int q = d / R1, rem = d - q * R1, h = rem & 3, sidx = rem >> 2, e = 8 * sidx + q;
+        const size_t tile = (size_t)cb * ntc + ct;
+        const size_t tm = ((tile * (NLB / 2) + (e >> 1)) * 64 + (16 * h + c)) * 2 + (e & 1);
+        if (TO_TM) out[tm] = in[idx]; else out[idx] = in[tm];
+    }
+}
+
 // -------------------------------------------------------------------------------------------
 // row pass (y direction), T = N/16 threads per transform, G = max(1, 256/T) row pairs per WG
 // -------------------------------------------------------------------------------------------
@@ -528,45 +548,78 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
             cf th[W::NLB];
             wave_fft_A2B<n, -1>(in, th, lds, a.tw_n, lane);               // main.cpp:237 (x part)
             if (lb) {
+                // state arrays in the tile-major layout (see state_tm_index): one float4 = elements e, e+1
+                const size_t sb = W::TM ? ((size_t)tile * (W::NLB / 2)) * 64 + lane : 0;
 #pragma unroll
-                for (int s = 0; s < W::NP; ++s)
+                for (int jp = 0; jp < W::NLB / 2; ++jp) {
+                    cf z0v[2], zcv[2], acv[2];
+                    if (W::TM) {
+                        const float4 t0 = reinterpret_cast<const float4 *>(a.Zbase)[sb + jp * 64];
+                        z0v[0] = cf_make(t0.x, t0.y); z0v[1] = cf_make(t0.z, t0.w);
+                        if (a.stage != 0) { const float4 t1 = reinterpret_cast<const float4 *>(a.Zcur)[sb + jp * 64];
+                                            zcv[0] = cf_make(t1.x, t1.y); zcv[1] = cf_make(t1.z, t1.w);
+                                            const float4 t2 = reinterpret_cast<const float4 *>(a.Acc)[sb + jp * 64];
+                                            acv[0] = cf_make(t2.x, t2.y); acv[1] = cf_make(t2.z, t2.w); }
+                    }
+                    cf accv[2], znv[2];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int e = s * 8 + q, d = h + 4 * s + W::R1 * q, ikx = cb + a.N1 * d;
+                    for (int u = 0; u < 2; ++u) {
+                        const int e = 2 * jp + u, s = e >> 3, q = e & 7;
+                        const int d = h + 4 * s + W::R1 * q, ikx = cb + a.N1 * d;
                         const size_t off = tbase + (size_t)d * a.P + c;
                         const float lap = (float)(-(a.coef.kx2[ikx] + ky2));
                         const float msk = coef_mask(a.coef, ikx, ky);
-                        const cf z0 = a.Zbase[off];
-                        const cf zc = a.stage == 0 ? z0 : a.Zcur[off];
+                        const cf z0 = W::TM ? z0v[u] : a.Zbase[off];
+                        const cf zc = a.stage == 0 ? z0 : (W::TM ? zcv[u] : a.Zcur[off]);
                         // dvortdt_c += lvort_c * NU ; rk = dealiase(dvortdt_c)   main.cpp:148,240-243,296
                         cf k = cf_make((th[e].x + (zc.x * lap) * a.nu) * msk, (th[e].y + (zc.y * lap) * a.nu) * msk);
                         cf acc, znew;
                         if (a.stage == 0) {            // main.cpp:296
                             acc = k; znew = cf_make(z0.x + k.x * (a.dt / 2.0f), z0.y + k.y * (a.dt / 2.0f));
                         } else if (a.stage == 1) {     // main.cpp:299
-                            const cf ac = a.Acc[off];
+                            const cf ac = W::TM ? acv[u] : a.Acc[off];
                             acc = cf_make(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y);
                             znew = cf_make(z0.x + k.x * (a.dt / 2.0f), z0.y + k.y * (a.dt / 2.0f));
                         } else if (a.stage == 2) {     // main.cpp:302
-                            const cf ac = a.Acc[off];
+                            const cf ac = W::TM ? acv[u] : a.Acc[off];
                             acc = cf_make(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y);
                             znew = cf_make(z0.x + k.x * a.dt, z0.y + k.y * a.dt);
                         } else {                       // main.cpp:309-312
-                            const cf ac = a.Acc[off];
+                            const cf ac = W::TM ? acv[u] : a.Acc[off];
                             acc = ac;
                             znew = cf_make(z0.x + (ac.x + k.x) * a.dt / 6.0f, z0.y + (ac.y + k.y) * a.dt / 6.0f);
                         }
-                        if (a.stage < 3) { a.Acc[off] = acc; a.Zcur[off] = znew; }
-                        else a.Zout[off] = znew;
+                        if (!W::TM) {
+                            if (a.stage < 3) { a.Acc[off] = acc; a.Zcur[off] = znew; }
+                            else a.Zout[off] = znew;
+                        }
+                        accv[u] = acc; znv[u] = znew;
                         zn[e] = znew;
                     }
+                    if (W::TM) {
+                        const float4 zo = make_float4(znv[0].x, znv[0].y, znv[1].x, znv[1].y);
+                        if (a.stage < 3) {
+                            reinterpret_cast<float4 *>(a.Acc)[sb + jp * 64] = make_float4(accv[0].x, accv[0].y, accv[1].x, accv[1].y);
+                            reinterpret_cast<float4 *>(a.Zcur)[sb + jp * 64] = zo;
+                        } else reinterpret_cast<float4 *>(a.Zout)[sb + jp * 64] = zo;
+                    }
+                }
             }
         } else if (lb) {
+            if (W::TM) {
+                const size_t sb = ((size_t)tile * (W::NLB / 2)) * 64 + lane;
 #pragma unroll
-            for (int s = 0; s < W::NP; ++s)
+                for (int jp = 0; jp < W::NLB / 2; ++jp) {
+                    const float4 t0 = reinterpret_cast<const float4 *>(a.Zbase)[sb + jp * 64];
+                    zn[2 * jp] = cf_make(t0.x, t0.y); zn[2 * jp + 1] = cf_make(t0.z, t0.w);
+                }
+            } else {
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    zn[s * 8 + q] = a.Zbase[tbase + (size_t)(h + 4 * s + W::R1 * q) * a.P + c];
+                for (int s = 0; s < W::NP; ++s)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        zn[s * 8 + q] = a.Zbase[tbase + (size_t)(h + 4 * s + W::R1 * q) * a.P + c];
+            }
         }
 
         // derivatives of zn through the backward block sub-pass: f0 gradx(vort), f1 grady(vort),

@@ -490,6 +490,18 @@ static int c2r_private(fb_ctx *c, cf *work, float *d_real, float scale)
     return launch_row<ROW_INV>(c, a);
 }
 
+// 3-pass row layout <-> the tile-major layout of the state arrays (out-of-place)
+static bool state_tm(const fb_ctx *c) { return c->N2 >= 32; }
+static int state_convert(fb_ctx *c, const cf *in, cf *out, bool to_tm)
+{
+    if (!state_tm(c)) { HIPCHK(hipMemcpyAsync(out, in, priv_elems(c) * sizeof(cf), hipMemcpyDeviceToDevice, c->stream)); return FB_OK; }
+    const size_t total = priv_elems(c);
+    if (to_tm) hipLaunchKernelGGL((k_state_relayout<true>), dim3(grid_for(c, total)), dim3(256), 0, c->stream, in, out, c->nx, c->P, c->N2);
+    else hipLaunchKernelGGL((k_state_relayout<false>), dim3(grid_for(c, total)), dim3(256), 0, c->stream, in, out, c->nx, c->P, c->N2);
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
 static int relayout(fb_ctx *c, const cf *in, cf *out, bool to_private)
 {
     const size_t total = priv_elems(c);
@@ -637,12 +649,13 @@ extern "C" int fb_model_set_vort(fb_model *m, const float *d_vort)
     if (!m || !d_vort) return fail(FB_EINVAL, "fb_model_set_vort: NULL");
     fb_ctx *c = m->c;
     NEED_SINGLE(c);
-    cf *dst = m->full ? m->ZB : m->ZA;                      // full path: via the 3-pass layout in ZB (stage scratch)
+    cf *dst = m->ZB;                                        // 3-pass row layout in ZB (stage scratch), then into ZA's layout
     HIPCHK(hipMemsetAsync(dst, 0, priv_elems(c) * sizeof(cf), c->stream));
     m->primed = false;
     int rc = r2c_private(c, d_vort, dst);                   // main.cpp:256
-    if (rc || !m->full) return rc;
-    return full_import_state(m, dst);
+    if (rc) return rc;
+    if (m->full) return full_import_state(m, dst);
+    return state_convert(c, dst, m->ZA, true);
 }
 
 extern "C" int fb_model_set_source(fb_model *m, const float *d_src)
@@ -684,7 +697,8 @@ static int full_import_state(fb_model *m, cf *spec3)
     fb_ctx *c = m->c;
     int rc;
     MidArgs a = mid_args(m, -1);
-    a.Zbase = spec3;
+    if ((rc = state_convert(c, spec3, m->ACC, true))) return rc;     // ACC is free here: tile-major copy for the priming pass
+    a.Zbase = m->ACC;
     if ((rc = launch_col_mid(c, a))) return rc;
     if ((rc = launch_col_strided<+1>(c, m->W4, 4, (long)priv_elems(c)))) return rc;
     hipLaunchKernelGGL((k_nyq_col<true>), dim3((c->nx + 255) / 256), dim3(256), 0, c->stream, spec3, m->znyq, c->nx, c->P, c->N1, c->N2, c->ny / 2);
@@ -815,13 +829,12 @@ extern "C" int fb_model_phase(fb_model *m, int phase, int stage, const float *d_
     }
     case FB_PH_R2C_COLS:                                    // t_recv -> vort_c (private layout)
         if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0)) || (rc = launch_col_block<-1>(c, m->t_recv, 1, 0))) return rc;
-        HIPCHK(hipMemcpyAsync(m->ZA, m->t_recv, E * sizeof(cf), hipMemcpyDeviceToDevice, c->stream));
         m->primed = false;
-        return FB_OK;
+        return state_convert(c, m->t_recv, m->ZA, true);
     case FB_PH_C2R_COLS:                                    // copy of vort_c -> x-inverse-transformed columns in t_recv
         m->primed = false;                                  // w4_send is clobbered
         // vort_c is staged in t_recv's buffer-sized scratch (field 0 region is destination-blocked in slab mode)
-        HIPCHK(hipMemcpyAsync(m->t_recv, m->ZA, E * sizeof(cf), hipMemcpyDeviceToDevice, c->stream));
+        if ((rc = state_convert(c, m->ZA, m->t_recv, false))) return rc;
         if ((rc = launch_col_block<+1>(c, m->t_recv, 1, 0))) return rc;
         if ((rc = launch_col_strided<+1>(c, m->t_recv, 1, 0))) return rc;      // natural [x][KS] == [dst][XL][KS]
         return FB_OK;
@@ -876,7 +889,9 @@ extern "C" int fb_model_get_spectrum(fb_model *m, float *d_spec)
         if ((rc = ensure_scratch(m->c)) || (rc = full_export_state(m, m->c->d_scratch))) return rc;
         return relayout(m->c, m->c->d_scratch, (cf *)d_spec, false);
     }
-    return relayout(m->c, m->ZA, (cf *)d_spec, false);
+    int rc;
+    if ((rc = ensure_scratch(m->c)) || (rc = state_convert(m->c, m->ZA, m->c->d_scratch, false))) return rc;
+    return relayout(m->c, m->c->d_scratch, (cf *)d_spec, false);
 }
 
 extern "C" int fb_model_set_spectrum(fb_model *m, const float *d_spec)
@@ -888,7 +903,8 @@ extern "C" int fb_model_set_spectrum(fb_model *m, const float *d_spec)
         int rc = relayout(m->c, (const cf *)d_spec, m->ZB, true);
         return rc ? rc : full_import_state(m, m->ZB);
     }
-    return relayout(m->c, (const cf *)d_spec, m->ZA, true);
+    int rc = relayout(m->c, (const cf *)d_spec, m->ZB, true);
+    return rc ? rc : state_convert(m->c, m->ZB, m->ZA, true);
 }
 
 extern "C" int fb_model_get_vort(fb_model *m, float *d_vort)
@@ -900,7 +916,7 @@ extern "C" int fb_model_get_vort(fb_model *m, float *d_vort)
     if ((rc = ensure_scratch(c))) return rc;
     // copy of vort_c (main.cpp:273), c2r, normalise (main.cpp:275)
     if (m->full) { if ((rc = full_export_state(m, c->d_scratch))) return rc; }
-    else HIPCHK(hipMemcpyAsync(c->d_scratch, m->ZA, priv_elems(c) * sizeof(cf), hipMemcpyDeviceToDevice, c->stream));
+    else if ((rc = state_convert(c, m->ZA, c->d_scratch, false))) return rc;
     return c2r_private(c, c->d_scratch, d_vort, 1.0f / (float)((size_t)c->nx * c->ny));
 }
 
