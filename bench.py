@@ -66,9 +66,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=4096, help="grid points per side")
+    ap.add_argument("--grid", "--n", dest="n", type=int, default=4096, help="grid points per side")
     ap.add_argument("--kind", default=None, help="initial field (default: kuo2004 for n>=4096 else elliptic)")
     ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
 
     import torch
@@ -79,7 +80,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                              % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))     # rehearsal on one GPU: ranks share it
 
     import xlab_fftbarotropic_amd as X
     n = args.n
@@ -89,7 +90,10 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(args.backend)
         from importlib import import_module
         slab = import_module("xlab-fftbarotropic_amd.slab")
         model = slab.SlabModel(n, n, dt=dt, rank=rank, world=world)

@@ -98,3 +98,54 @@ def test_slab_model_world1_api():
     ref.set_vort(v0)
     ref.step(4)
     assert np.array_equal(m.vort_local().cpu().numpy().view(np.uint32), ref.vort().cpu().numpy().view(np.uint32))
+
+
+def test_bench_two_ranks_on_one_gpu_gloo(tmp_path):
+    """The real multi-process flow of bench.py (torch.distributed.run, SlabModel + HipBackend, exchange
+    between phases) with 2 ranks sharing the GPU over gloo -- RCCL itself needs two devices."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--grid", "512", "--backend", "gloo", "--cpu-steps", "0"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "slab2"
+
+
+def test_slab_model_two_ranks_gloo_matches_single(tmp_path):
+    """SlabModel on 2 processes (one GPU, gloo) reproduces the single-process field bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from importlib import import_module\n"
+        "import xlab_fftbarotropic_amd as X\n"
+        "slab = import_module('xlab-fftbarotropic_amd.slab')\n"
+        "torch.cuda.set_device(0); dist.init_process_group('gloo')\n"
+        "r, w = dist.get_rank(), dist.get_world_size(); n = 256\n"
+        "v0 = X.make_field('elliptic', n)\n"
+        "m = slab.SlabModel(n, n, rank=r, world=w); m.set_vort_local(slab.local_rows(v0, r, w)); m.step(3)\n"
+        "np.save(os.path.join(%r, 'rows%%d.npy' %% r), m.vort_local().cpu().numpy())\n"
+        "dist.destroy_process_group()\n" % (root, str(tmp_path)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29618", str(script)]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    import xlab_fftbarotropic_amd as X
+    n = 256
+    ref = X.Model(n, n)
+    ref.set_vort(X.make_field("elliptic", n))
+    ref.step(3)
+    want = ref.vort().cpu().numpy()
+    got = np.concatenate([np.load(str(tmp_path / ("rows%d.npy" % r))) for r in range(2)], axis=0)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
