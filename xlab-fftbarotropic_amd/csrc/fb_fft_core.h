@@ -70,23 +70,28 @@ template <int DIR> struct Bfly<8, DIR> {
         v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
     }
 };
+// scheduling fence: the four independent radix-4 sub-butterflies of a radix-16 are NOT interleaved
+// by the machine scheduler (one set of temporaries instead of four) -- on these register-bound
+// kernels occupancy is worth more than intra-wave ILP
+#define FB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 template <int DIR> struct Bfly<16, DIR> {
     static FB_DEV void run(cf *v)
     {
         // x[4 n1 + n2]: column n2 transformed over n1
-        fft4<DIR>(v[0], v[4], v[8], v[12]);
-        fft4<DIR>(v[1], v[5], v[9], v[13]);
-        fft4<DIR>(v[2], v[6], v[10], v[14]);
-        fft4<DIR>(v[3], v[7], v[11], v[15]);
+        fft4<DIR>(v[0], v[4], v[8], v[12]);  FB_SCHED_FENCE();
+        fft4<DIR>(v[1], v[5], v[9], v[13]);  FB_SCHED_FENCE();
+        fft4<DIR>(v[2], v[6], v[10], v[14]); FB_SCHED_FENCE();
+        fft4<DIR>(v[3], v[7], v[11], v[15]); FB_SCHED_FENCE();
         // now v[4 k1 + n2] = Y_{n2}[k1]; twiddle W16^{n2 k1}
         v[5]  = mul_w16<1, DIR>(v[5]);  v[6]  = mul_w16<2, DIR>(v[6]);  v[7]  = mul_w16<3, DIR>(v[7]);
         v[9]  = mul_w16<2, DIR>(v[9]);  v[10] = mul_w16<4, DIR>(v[10]); v[11] = mul_w16<6, DIR>(v[11]);
         v[13] = mul_w16<3, DIR>(v[13]); v[14] = mul_w16<6, DIR>(v[14]); v[15] = mul_w16<9, DIR>(v[15]);
+        FB_SCHED_FENCE();
         // transform over n2 for each k1 -> X[k1 + 4 k2] lands in v[4 k1 + k2]
-        fft4<DIR>(v[0], v[1], v[2], v[3]);
-        fft4<DIR>(v[4], v[5], v[6], v[7]);
-        fft4<DIR>(v[8], v[9], v[10], v[11]);
-        fft4<DIR>(v[12], v[13], v[14], v[15]);
+        fft4<DIR>(v[0], v[1], v[2], v[3]);     FB_SCHED_FENCE();
+        fft4<DIR>(v[4], v[5], v[6], v[7]);     FB_SCHED_FENCE();
+        fft4<DIR>(v[8], v[9], v[10], v[11]);   FB_SCHED_FENCE();
+        fft4<DIR>(v[12], v[13], v[14], v[15]); FB_SCHED_FENCE();
         // transpose 4x4: want v[k1 + 4 k2]
         cf t;
         t = v[1];  v[1]  = v[4];  v[4]  = t;
@@ -360,4 +365,74 @@ FB_DEV void row_fft(cf *lds, int t, const SRC &src, cf *reg)
         stockham_stage<N, TW::radix(2), TW::ns(2), DIR, false, false, 2>(lds, launder(t), src, reg);
         stockham_stage<N, TW::radix(3), TW::ns(3), DIR, false, true, 3>(lds, launder(t), src, reg);
     }
+}
+
+
+// ============================================================================================
+// Half-buffer variant of the row transform: the LDS exchange between two stages is done in two
+// rounds over a buffer of N/2 elements (positions [0,N/2) first, then [N/2,N)), which halves the
+// exchange LDS of a workgroup (more workgroups per CU) for two extra barriers per exchange.
+// Writers of stage s land in the first half iff their butterfly index j < N/(2R); readers of
+// stage s+1 take their inputs q' < R'/2 from the first half.
+// ============================================================================================
+template <int N, int R, int NS, int DIR, int SI, class SRC>
+FB_DEV void stage_compute(int t, const SRC &src, cf *reg)
+{
+    constexpr int T = N / 16, NB = 16 / R;
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+        cf *v = reg + m * R;
+        if (NS > 1) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) v[q] = cmul_dir<DIR>(v[q], src.template get<SI>(m * (R - 1) + (q - 1)));
+        }
+        Bfly<R, DIR>::run(v);
+    }
+    (void)T; (void)t;
+}
+
+// exchange: outputs of a radix-R stage with stride NS  ->  inputs of the next stage of radix R2
+template <int N, int R, int NS, int R2>
+FB_DEV void stage_exchange_half(cf *lds, int t, cf *reg)
+{
+    constexpr int T = N / 16, NB = 16 / R, NB2 = 16 / R2, STR2 = N / R2, HALF = N / 2;
+    cf out[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e] = reg[e];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        lds_barrier();                                              // previous readers are done
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const int j = t + m * T;
+            if ((j < N / (2 * R)) == (half == 0)) {
+                const int j0 = (j / NS) * NS * R + (j % NS) - half * HALF;
+#pragma unroll
+                for (int q = 0; q < R; ++q) lds[lds_pad(j0 + q * NS)] = out[m * R + q];
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int m = 0; m < NB2; ++m) {
+            const int j = t + m * T;
+#pragma unroll
+            for (int q = 0; q < R2 / 2; ++q) {
+                const int qq = q + half * (R2 / 2);
+                reg[m * R2 + qq] = lds[lds_pad(j + qq * STR2 - half * HALF)];
+            }
+        }
+    }
+}
+
+template <int N, bool FWD, class SRC>
+FB_DEV void row_fft_half(cf *lds, int t, const SRC &src, cf *reg)
+{
+    using TW = RowTw<N, FWD>;
+    constexpr int S = RowPlan<N>::S, DIR = FWD ? -1 : +1;
+    static_assert(S == 3, "half-buffer row transform is instantiated for three-stage plans");
+    stage_compute<N, TW::radix(0), 1, DIR, 0>(launder(t), src, reg);
+    stage_exchange_half<N, TW::radix(0), 1, TW::radix(1)>(lds, launder(t), reg);
+    stage_compute<N, TW::radix(1), TW::ns(1), DIR, 1>(launder(t), src, reg);
+    stage_exchange_half<N, TW::radix(1), TW::ns(1), TW::radix(2)>(lds, launder(t), reg);
+    stage_compute<N, TW::radix(2), TW::ns(2), DIR, 2>(launder(t), src, reg);
 }

@@ -154,7 +154,9 @@ template <int N> struct RowCfg {
     static constexpr int T = N / 16;
     static constexpr int G = T >= 256 ? 1 : 256 / T;
     static constexpr int THREADS = T * G;
-    static constexpr int LSTR = N + N / 16;               // padded complex per group (exchange buffer)
+    // half-buffer exchange (row_fft_half): 51 KiB per workgroup at N = 4096 -> three workgroups per CU
+    static constexpr bool HALFX = false;   // measured at N = 4096: 0.205 ms vs 0.104 ms with the full buffer
+    static constexpr int LSTR = HALFX ? (N / 2 + N / 32) : (N + N / 16);   // padded complex per group (exchange buffer)
     // LDS-DMA prefetch of the next phase's two half-spectrum rows (fused mode): groups must be
     // whole waves and buffer + staging must leave room for two workgroups per CU
     static constexpr bool DMA = N >= 1024 && N <= 8192;
@@ -163,7 +165,7 @@ template <int N> struct RowCfg {
     static constexpr bool SHARE = RES && RowPlanSymmetric<N>::value;        // one twiddle set for both directions
     static constexpr int TWL_B = RowTwSrc<N, false, RES>::LDS_CF, TWL_F = SHARE ? 0 : RowTwSrc<N, true, RES>::LDS_CF;
     static constexpr size_t LDS_BYTES = ((size_t)G * GSTR + TWL_B + TWL_F) * sizeof(cf);
-    static constexpr int MIN_WAVES = THREADS == 256 ? 2 : (THREADS == 512 ? 2 : 4);
+    static constexpr int MIN_WAVES = HALFX ? 3 : (THREADS == 256 ? 2 : (THREADS == 512 ? 2 : 4));
 };
 
 // element (row, k) of a mixed-space array; SLAB: the row is cut into ky slabs of ks columns that
@@ -205,11 +207,12 @@ template <int N, bool SLAB>
 FB_DEV void row_store_pair(cf *lds, int t, const cf *reg, bool valid, cf *T_, int rowA, int rowB, int ks, long sstride)
 {
     constexpr int T = N / 16, RL = RowTw<N, true>::radix(RowPlan<N>::S - 1);
+    constexpr int HOFF = RowCfg<N>::HALFX ? N / 2 : 0;           // only positions >= N/2 go through LDS
     lds_barrier();
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int i = ord_i<RL>(e);
-        if (i >= 8) lds[lds_pad(t + i * T)] = reg[e];
+        if (i >= 8) lds[lds_pad(t + i * T - HOFF)] = reg[e];
     }
     lds_barrier();
     if (!valid) return;
@@ -219,7 +222,7 @@ FB_DEV void row_store_pair(cf *lds, int t, const cf *reg, bool valid, cf *T_, in
         if (i < 8) {
             const int k = t + i * T;
             const cf zk = reg[e];
-            const cf zn = (i == 0 && t == 0) ? zk : lds[lds_pad(N - k)];
+            const cf zn = (i == 0 && t == 0) ? zk : lds[lds_pad(N - k - HOFF)];
             *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, k)) = cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
             *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, k)) = cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
         } else if (i == 8 && t == 0) {                       // Nyquist: its own mirror
@@ -269,6 +272,13 @@ FB_DEV void row_ext_from_stage(cf *reg, int t, const cf *stg, cf nyqA, cf nyqB)
             reg[e] = nyq ? cf_make(nyqA.x, nyqB.x) : cf_make(a.x + b.y, b.x - a.y);
         }
     }
+}
+
+template <int N, bool FWD, class SRC>
+FB_DEV void rowfft(cf *lds, int t, const SRC &src, cf *reg)
+{
+    if constexpr (RowCfg<N>::HALFX) row_fft_half<N, FWD>(lds, t, src, reg);
+    else row_fft<N, FWD>(lds, t, src, reg);
 }
 
 template <int N, int MODE, bool SLAB>
@@ -326,7 +336,7 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
                 } else {
                     row_load_pair<N, SLAB>(reg, launder(t), a.M, a.M + a.m_fstride, x, x, a.ks, a.m_sstride);
                 }
-                row_fft<N, false>(lds, launder(t), twb, reg);
+                rowfft<N, false>(lds, launder(t), twb, reg);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { zx[e] = reg[e].x * a.scale; zy[e] = reg[e].y * a.scale; }   // main.cpp:154,168
                 // ---- phase (r, 1): u, v of row x
@@ -341,7 +351,7 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
                 } else {
                     row_load_pair<N, SLAB>(reg, launder(t), a.M + 2 * a.m_fstride, a.M + 3 * a.m_fstride, x, x, a.ks, a.m_sstride);
                 }
-                row_fft<N, false>(lds, launder(t), twb, reg);
+                rowfft<N, false>(lds, launder(t), twb, reg);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float u = -(reg[e].x * a.scale);            // main.cpp:200-201
@@ -361,12 +371,12 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
         }
 
         if (MODE == ROW_FUSED || MODE == ROW_FWD) {
-            if constexpr (SHARE) row_fft<N, true>(lds, launder(t), reinterpret_cast<const RowTwSrc<N, true, true> &>(twb), reg);   // main.cpp:237 (y part)
-            else row_fft<N, true>(lds, launder(t), twf_own, reg);
+            if constexpr (SHARE) rowfft<N, true>(lds, launder(t), reinterpret_cast<const RowTwSrc<N, true, true> &>(twb), reg);   // main.cpp:237 (y part)
+            else rowfft<N, true>(lds, launder(t), twf_own, reg);
             row_store_pair<N, SLAB>(lds, launder(t), reg, valid, a.T, x0, x1, a.ks, a.t_sstride);
         } else {
             row_load_pair<N, SLAB>(reg, launder(t), a.M, a.M, x0, x1, a.ks, a.m_sstride);
-            row_fft<N, false>(lds, launder(t), twb, reg);
+            rowfft<N, false>(lds, launder(t), twb, reg);
             if (valid) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
