@@ -21,7 +21,7 @@ def test_host_programs_link():
     import xlab_fftbarotropic_amd as X
     X.build_lib()
     _build()
-    for exe in ("barotropic_main.out", "shim_check.out", "invert_pres.out"):
+    for exe in ("barotropic_main.out", "shim_check.out", "invert_pres.out", "vort_src_input.out"):
         assert os.access(os.path.join(HOST, exe), os.X_OK)
 
 
@@ -165,3 +165,49 @@ def test_invert_pres_against_oracle_pipeline(tmp_path):
         pres = pres - pres.ravel()[3 + n * 5]
         got = np.fromfile(str(tmp_path / "output" / ("pres_step_%d.bin" % step)), dtype="<f4").reshape(n, n)
         assert R.rel_l2(got, pres) < 1e-4, step          # two chained 2-D FFT round trips of an ill-scaled field
+
+
+def test_fifo_producer_stream_matches_reference_and_oracle():
+    """host/vort_src_input.cpp against (a) the reference-built producer's byte stream at its compiled-in
+    configuration (768^2, dt = 3, 1200 steps: all flags 0 because beg_step = 2400 > 1200) and (b) the
+    oracle's cake when the window is inside the run.  Host-only: runs without a GPU."""
+    import hashlib
+    import json
+    import oracle_py as O
+    _build()
+    meta = json.load(open(os.path.join(HERE, "golden", "ref_meta.json")))
+    exe = os.path.join(HOST, "vort_src_input.out")
+    raw = subprocess.run([exe, "--npts", "768", "--dt", "3", "--steps", "1200"], stdout=subprocess.PIPE,
+                         stderr=subprocess.DEVNULL, check=True).stdout
+    assert hashlib.sha256(raw).hexdigest() == meta["fifo_stream"]["sha256"] and len(raw) == 1199
+    n = 64
+    raw = subprocess.run([exe, "--npts", str(n), "--dt", "3", "--steps", "12", "--beg-time", "9", "--duration", "12"],
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    src = np.zeros((n, n), dtype=np.float32)
+    O.add_cake(src, 6e5, 6e5, 6e5 / 2 + 5e4, 6e5 / 2, np.float32(3e-3 / np.float32(12.0)), 3e4)
+    want = b"\x00" * 2 + b"\x01" + src.tobytes() + b"\x00" * 3 + b"\x01" + np.zeros_like(src).tobytes() + b"\x00" * 4
+    assert raw == want                      # steps 1..11: on at step 3 (= 9 s / 3 s), off at step 7
+
+
+@pytest.mark.gpu
+def test_driver_restart_with_start_step(tmp_path):
+    """--start-step: restarting from vort_step_100.bin continues numbering and reproduces the
+    uninterrupted run's later dumps to rounding (the restart goes through one extra c2r/r2c pair)."""
+    import oracle_py as O
+    import ref_numpy as R
+    _build()
+    n = 256
+    for d in ("a", "b"):
+        (tmp_path / d / "input").mkdir(parents=True)
+        (tmp_path / d / "output").mkdir()
+    O.make_field("elliptic", n).tofile(str(tmp_path / "a" / "input" / "initial_vorticity.bin"))
+    exe = os.path.join(HOST, "barotropic_main.out")
+    run = lambda cwd, extra: subprocess.check_call([exe, "--npts", str(n)] + extra, cwd=str(tmp_path / cwd),
+                                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    run("a", ["--steps", "201"])
+    os.link(str(tmp_path / "a" / "output" / "vort_step_100.bin"), str(tmp_path / "b" / "input" / "vort_step_100.bin"))
+    run("b", ["-i", "vort_step_100.bin", "--start-step", "100", "--steps", "201"])
+    assert sorted(os.listdir(str(tmp_path / "b" / "output"))) == sorted(
+        "%s_step_%d.bin" % (nm, s) for s in (100, 200) for nm in ("vort_src_input", "vort", "psi", "u", "v"))
+    rd = lambda d, f: np.fromfile(str(tmp_path / d / "output" / f), dtype="<f4")
+    assert R.rel_l2(rd("b", "vort_step_200.bin"), rd("a", "vort_step_200.bin")) < 2e-6

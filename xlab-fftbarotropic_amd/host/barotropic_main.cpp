@@ -59,11 +59,11 @@ int main(int argc, char *args[])
 {
     // configuration.hpp:10-41 defaults (NPTS 768 is not a power of two: see DESIGN.md, "out of scope")
     std::string input = "input", output = "output", init_file = "initial_vorticity.bin", vort_src_filename;
-    int npts = 1024, record_step = 100, total_steps = -1;
+    int npts = 1024, record_step = 100, total_steps = -1, start_step = 0;
     float LX = 600000.0f, LY = 600000.0f, NU = 6.5f, dt = 3.0f;
     RECIPE_TYPE recipe_type = EMPTY;
     static struct option lopts[] = {{"npts", 1, 0, 1}, {"lx", 1, 0, 2}, {"ly", 1, 0, 3}, {"nu", 1, 0, 4}, {"dt", 1, 0, 5},
-                                    {"steps", 1, 0, 6}, {"record-step", 1, 0, 7}, {0, 0, 0, 0}};
+                                    {"steps", 1, 0, 6}, {"record-step", 1, 0, 7}, {"start-step", 1, 0, 8}, {0, 0, 0, 0}};
     int opt;
     while ((opt = getopt_long(argc, args, "I:O:i:s:f:", lopts, NULL)) != EOF) {      // main.cpp:68-80, main-shallow-water.cpp:75-95
         switch (opt) {
@@ -79,6 +79,7 @@ int main(int argc, char *args[])
         case 5: dt = (float)atof(optarg); break;
         case 6: total_steps = atoi(optarg); break;
         case 7: record_step = atoi(optarg); break;
+        case 8: start_step = atoi(optarg); break;    // restart: -i vort_step_N.bin --start-step N keeps file numbering and source timing
         }
     }
     if (total_steps < 0) total_steps = (int)(60 * 60 / dt);                          // configuration.hpp:36
@@ -128,7 +129,9 @@ int main(int argc, char *args[])
     };
 
     int record_flag = 0;
-    for (int step = 0; step < total_steps; ++step) {                                   // main.cpp:260
+    // The reference can be restarted from any vort_step_N.bin via -i, but always renumbers from 0
+    // (SURVEY section 5); --start-step N continues the numbering and the source clock instead.
+    for (int step = start_step; step < total_steps; ++step) {                          // main.cpp:260
         printf("# Step %d, time = %.2f", step, step * dt);
         if ((record_flag = ((step % record_step) == 0))) printf(", record now!");
         printf("\n");
