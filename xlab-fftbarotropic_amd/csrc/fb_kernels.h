@@ -405,6 +405,7 @@ struct ColArgs {
     cf *data;          // field f at data + f*fstride (+ row map)
     long fstride;
     RowMap rm;
+    int ct0, nct;      // column tiles [ct0, ct0+nct) are processed (frozen high-ky tiles are skipped per stage)
     int nfields;
     int P;             // pitch (complex)
     int N1, N2;        // nx = N1*N2
@@ -420,14 +421,14 @@ __global__ void __launch_bounds__(256) k_col_strided(ColArgs a)
     __shared__ __attribute__((aligned(16))) cf smem[4 * W::LDS_CF];
     const int wv = threadIdx.x >> 6;
     cf *lds = smem + wv * W::LDS_CF;
-    const int ntc = a.P >> 4;
+    const int ntc = a.nct;
     const long ntiles = (long)a.nfields * a.N2 * ntc;
     for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
         const int lane = launder((int)(threadIdx.x & 63));
         const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
         const int f = (int)(tile / ((long)a.N2 * ntc));
         const int rem = (int)(tile - (long)f * a.N2 * ntc);
-        const int b = rem / ntc, ct = rem - b * ntc;
+        const int b = rem / ntc, ct = a.ct0 + rem - b * ntc;
         cf *base = a.data + (size_t)f * a.fstride + ct * 16;
         float4 in[W::NLA];
 #pragma unroll
@@ -456,14 +457,14 @@ __global__ void __launch_bounds__(256) k_col_block(ColArgs a)
     __shared__ __attribute__((aligned(16))) cf smem[4 * W::LDS_CF];
     const int wv = threadIdx.x >> 6;
     cf *lds = smem + wv * W::LDS_CF;
-    const int ntc = a.P >> 4;
+    const int ntc = a.nct;
     const long ntiles = (long)a.nfields * a.N1 * ntc;
     for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
         const int lane = launder((int)(threadIdx.x & 63));
         const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
         const int f = (int)(tile / ((long)a.N1 * ntc));
         const int rem = (int)(tile - (long)f * a.N1 * ntc);
-        const int cb = rem / ntc, ct = rem - cb * ntc;
+        const int cb = rem / ntc, ct = a.ct0 + rem - cb * ntc;
         cf *base = a.data + (size_t)f * a.fstride + (size_t)cb * n * a.P + ct * 16;
         if (DIR < 0) {
             float4 in[W::NLA];
@@ -517,6 +518,7 @@ struct MidArgs {
     cf *W4;              // four derived fields, field f at W4 + f*fstride (+ row map)
     long fstride;
     RowMap rm;
+    int ct0, nct;        // column-tile range
     int P, N1, N2;
     int ky0;             // global ky of local column 0 (slab offset)
     int stage;           // 0..3 RK stage whose tendency arrives; -1 = derive only (prime the pipeline)
@@ -532,14 +534,15 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
     __shared__ __attribute__((aligned(16))) cf smem[4 * W::LDS_CF];
     const int wv = threadIdx.x >> 6;
     cf *lds = smem + wv * W::LDS_CF;
-    const int ntc = a.P >> 4;
+    const int ntc = a.nct, ntc_all = a.P >> 4;
     const long ntiles = (long)a.N1 * ntc;
-    for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
+    for (long wt = (long)blockIdx.x * 4 + wv; wt < ntiles; wt += (long)gridDim.x * 4) {
         // per-tile opaque lane id: keeps address/coefficient arithmetic out of loop-invariant registers
         const int lane = launder((int)(threadIdx.x & 63));
         const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
         const bool lb = W::lb_active(lane);
-        const int cb = (int)(tile / ntc), ct = (int)(tile - (long)cb * ntc);
+        const int cb = (int)(wt / ntc), ct = a.ct0 + (int)(wt - (long)cb * ntc);
+        const long tile = (long)cb * ntc_all + ct;              // index of the tile in the tile-major state arrays
         const size_t tbase = (size_t)cb * n * a.P + ct * 16;
         const int col = ct * 16 + c, ky = a.ky0 + col;
         const float gy = a.coef.gy[ky];
@@ -563,10 +566,17 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
 #pragma unroll
                 for (int jp = 0; jp < W::NLB / 2; ++jp) {
                     cf z0v[2], zcv[2], acv[2];
+                    // modes outside the dealiasing circle never change (SURVEY note N1): when all 128 elements
+                    // of this wave instruction are masked, the stage state and the accumulator are not touched
+                    bool frozen = false;
                     if (W::TM) {
+                        const int d0 = h + 4 * ((2 * jp) >> 3) + W::R1 * ((2 * jp) & 7), d1 = h + 4 * ((2 * jp + 1) >> 3) + W::R1 * ((2 * jp + 1) & 7);
+                        const bool mine = coef_mask(a.coef, cb + a.N1 * d0, ky) == 0.0f && coef_mask(a.coef, cb + a.N1 * d1, ky) == 0.0f;
+                        frozen = __all(mine);
                         const float4 t0 = reinterpret_cast<const float4 *>(a.Zbase)[sb + jp * 64];
                         z0v[0] = cf_make(t0.x, t0.y); z0v[1] = cf_make(t0.z, t0.w);
-                        if (a.stage != 0) { const float4 t1 = reinterpret_cast<const float4 *>(a.Zcur)[sb + jp * 64];
+                        if (frozen) { zcv[0] = z0v[0]; zcv[1] = z0v[1]; acv[0] = acv[1] = cf_make(0.f, 0.f); }
+                        else if (a.stage != 0) { const float4 t1 = reinterpret_cast<const float4 *>(a.Zcur)[sb + jp * 64];
                                             zcv[0] = cf_make(t1.x, t1.y); zcv[1] = cf_make(t1.z, t1.w);
                                             const float4 t2 = reinterpret_cast<const float4 *>(a.Acc)[sb + jp * 64];
                                             acv[0] = cf_make(t2.x, t2.y); acv[1] = cf_make(t2.z, t2.w); }
@@ -606,7 +616,7 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
                         accv[u] = acc; znv[u] = znew;
                         zn[e] = znew;
                     }
-                    if (W::TM) {
+                    if (W::TM && !frozen) {
                         const float4 zo = make_float4(znv[0].x, znv[0].y, znv[1].x, znv[1].y);
                         if (a.stage < 3) {
                             reinterpret_cast<float4 *>(a.Acc)[sb + jp * 64] = make_float4(accv[0].x, accv[0].y, accv[1].x, accv[1].y);

@@ -59,6 +59,7 @@ struct fb_ctx {
     // device tables
     float *d_gx; double *d_kx2; float *d_gy; double *d_ky2; double gws;
     cf *d_tw_n1, *d_tw_n2, *d_tw_big, *d_tw_row_bwd, *d_tw_row_fwd, *d_tw_256;
+    int nct_active;             // local column tiles that contain at least one unmasked ky (the rest is frozen forever)
     bool nyq_frozen;            // the ky = ny/2 column lies outside the dealiasing circle (always on square grids)
     cf *d_scratch;              // nx*P complex, lazily allocated (standalone r2c / c2r)
     // host copies of the 1-D tables (fb_get_tables)
@@ -188,6 +189,13 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
     c->gws = (double)(float)((double)dxw * dxw + (double)dyw * dyw);              // :57
 
     c->nyq_frozen = ((double)(ny / 2) * (double)(ny / 2) >= c->gws);
+    {   // first ky with ky^2 >= gws: every mode of that column and beyond is masked (fftwfop.cpp:57-61)
+        int jmax = 0;
+        while (jmax < c->hy && (double)jmax * (double)jmax < c->gws) ++jmax;
+        int act = (jmax - c->ky0 + 15) / 16;
+        c->nct_active = act < 0 ? 0 : (act > c->P / 16 ? c->P / 16 : act);
+        if (getenv("FB_NO_COLUMN_SKIP")) c->nct_active = c->P / 16;
+    }
     int rc;
     if ((rc = upload(&c->d_gx, c->h_gx)) || (rc = upload(&c->d_kx2, c->h_kx2)) ||
         (rc = upload(&c->d_gy, c->h_gy)) || (rc = upload(&c->d_ky2, c->h_ky2)) ||
@@ -399,11 +407,13 @@ static RowMap rowmap_w4(const fb_ctx *c)
 }
 static long w4_fstride(const fb_ctx *c) { return c->world == 1 ? (long)c->nx * c->P : (long)c->XL * c->P; }
 
-template <int DIR> static int launch_col_strided(fb_ctx *c, cf *data, int nfields, long fstride, RowMap rm = rowmap_natural())
+template <int DIR> static int launch_col_strided(fb_ctx *c, cf *data, int nfields, long fstride, RowMap rm = rowmap_natural(), int ct0 = 0, int nct = -1)
 {
-    ColArgs a; a.data = data; a.fstride = fstride; a.rm = rm; a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
+    if (nct < 0) nct = c->P / 16 - ct0;
+    if (nct == 0) return FB_OK;
+    ColArgs a; a.data = data; a.fstride = fstride; a.rm = rm; a.ct0 = ct0; a.nct = nct; a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
     a.tw_n = c->d_tw_n1; a.tw_big = c->d_tw_big;
-    const long ntiles = (long)nfields * c->N2 * (c->P / 16);
+    const long ntiles = (long)nfields * c->N2 * nct;
     const dim3 g(col_grid(c, ntiles)), b(256);
     switch (c->N1) {
     case 8: hipLaunchKernelGGL((k_col_strided<8, DIR>), g, b, 0, c->stream, a); break;
@@ -419,7 +429,7 @@ template <int DIR> static int launch_col_strided(fb_ctx *c, cf *data, int nfield
 
 template <int DIR> static int launch_col_block(fb_ctx *c, cf *data, int nfields, long fstride)
 {
-    ColArgs a; a.data = data; a.fstride = fstride; a.rm = rowmap_natural(); a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
+    ColArgs a; a.data = data; a.fstride = fstride; a.rm = rowmap_natural(); a.ct0 = 0; a.nct = c->P / 16; a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
     a.tw_n = c->d_tw_n2; a.tw_big = c->d_tw_big;
     const long ntiles = (long)nfields * c->N1 * (c->P / 16);
     const dim3 g(col_grid(c, ntiles)), b(256);
@@ -437,7 +447,8 @@ template <int DIR> static int launch_col_block(fb_ctx *c, cf *data, int nfields,
 
 static int launch_col_mid(fb_ctx *c, const MidArgs &a)
 {
-    const long ntiles = (long)c->N1 * (c->P / 16);
+    if (a.nct == 0) return FB_OK;
+    const long ntiles = (long)c->N1 * a.nct;
     const dim3 g(col_grid(c, ntiles)), b(256);
     switch (c->N2) {
     case 8: hipLaunchKernelGGL((k_col_mid<8>), g, b, 0, c->stream, a); break;
@@ -674,6 +685,7 @@ static MidArgs mid_args(fb_model *m, int stage)
     fb_ctx *c = m->c;
     MidArgs a;
     a.Tin = m->t_recv; a.Zbase = m->ZA; a.Zcur = m->ZB; a.Acc = m->ACC; a.Zout = m->ZA; a.W4 = m->w4_send;
+    a.ct0 = 0; a.nct = stage < 0 ? c->P / 16 : c->nct_active;     // priming covers every column once
     a.fstride = w4_fstride(c); a.rm = rowmap_w4(c); a.P = c->P; a.N1 = c->N1; a.N2 = c->N2; a.ky0 = c->ky0; a.stage = stage;
     a.nu = m->nu; a.dt = m->dt; a.coef = make_coef(c); a.tw_n = c->d_tw_n2; a.tw_big = c->d_tw_big;
     return a;
@@ -739,6 +751,17 @@ static int launch_col_full(fb_model *m, int stage)
     return FB_OK;
 }
 
+// priming: derivatives of vort_c for every column; the frozen high-ky tiles get their backward strided
+// sub-pass here, once -- the per-stage passes only touch the active tiles
+static int model_prime(fb_model *m)
+{
+    fb_ctx *c = m->c;
+    int rc;
+    if ((rc = launch_col_mid(c, mid_args(m, -1)))) return rc;
+    m->primed = true;
+    return launch_col_strided<+1>(c, m->w4_send, 4, w4_fstride(c), rowmap_w4(c), c->nct_active, c->P / 16 - c->nct_active);
+}
+
 // optional per-launch HIP-event profiler (bench.py's roofline leg)
 struct StepProf {
     std::vector<hipEvent_t> ev0[4], ev1[4];
@@ -758,10 +781,7 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
     int rc;
     if (nsteps == 0) return FB_OK;
     if (m->full && !m->primed) return fail(FB_EINVAL, "fb_model_step: set the state first");
-    if (!m->primed) {
-        if ((rc = launch_col_mid(c, mid_args(m, -1)))) return rc;
-        m->primed = true;
-    }
+    if (!m->primed && (rc = model_prime(m))) return rc;
     const float scale = 1.0f / (float)((size_t)c->nx * c->ny);
     for (int s = 0; s < nsteps; ++s) {
         for (int k = 0; k < 4; ++k) {
@@ -777,7 +797,7 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
                 continue;
             }
             PROF_BEGIN(0);
-            if ((rc = launch_col_strided<+1>(c, m->w4_send, 4, (long)priv_elems(c)))) return rc;
+            if ((rc = launch_col_strided<+1>(c, m->w4_send, 4, (long)priv_elems(c), rowmap_natural(), 0, c->nct_active))) return rc;
             PROF_END(0);
             RowArgs a = row_args_base(c);
             a.M = m->w4_recv; a.m_fstride = (long)priv_elems(c); a.T = m->t_send; a.src = m->src; a.scale = scale;
@@ -785,7 +805,7 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
             if ((rc = launch_row<ROW_FUSED>(c, a))) return rc;
             PROF_END(1);
             PROF_BEGIN(2);
-            if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0))) return rc;
+            if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0, rowmap_natural(), 0, c->nct_active))) return rc;
             PROF_END(2);
             PROF_BEGIN(3);
             if ((rc = launch_col_mid(c, mid_args(m, k)))) return rc;
@@ -808,10 +828,9 @@ extern "C" int fb_model_phase(fb_model *m, int phase, int stage, const float *d_
     int rc;
     switch (phase) {
     case FB_PH_PRIME:                                       // derivatives of vort_c -> w4_send (block sub-pass done)
-        m->primed = true;
-        return launch_col_mid(c, mid_args(m, -1));
+        return model_prime(m);
     case FB_PH_COL_BWD:                                     // strided backward sub-pass on the 4 fields (in w4_send)
-        return launch_col_strided<+1>(c, m->w4_send, 4, w4_fstride(c), rowmap_w4(c));
+        return launch_col_strided<+1>(c, m->w4_send, 4, w4_fstride(c), rowmap_w4(c), 0, c->nct_active);
     case FB_PH_ROW: {                                       // w4_recv (row slabs) -> tendency rows in t_send
         RowArgs a = row_args_base(c);
         a.M = m->w4_recv; a.m_fstride = w4_fstride(c); a.T = m->t_send; a.src = m->src; a.scale = scale;
@@ -820,7 +839,7 @@ extern "C" int fb_model_phase(fb_model *m, int phase, int stage, const float *d_
     }
     case FB_PH_COL_FWD:                                     // t_recv (column slab) -> forward x pass + RK update + derivatives
         if (stage < 0 || stage > 3) return fail(FB_EINVAL, "fb_model_phase: stage");
-        if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0))) return rc;
+        if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0, rowmap_natural(), 0, c->nct_active))) return rc;
         return launch_col_mid(c, mid_args(m, stage));
     case FB_PH_R2C_ROWS: {                                  // local real rows -> y-transformed rows in t_send
         if (!d_real_in) return fail(FB_EINVAL, "fb_model_phase: d_real_in NULL");
