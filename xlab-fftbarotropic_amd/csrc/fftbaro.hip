@@ -59,6 +59,7 @@ struct fb_ctx {
     // device tables
     float *d_gx; double *d_kx2; float *d_gy; double *d_ky2; double gws;
     cf *d_tw_n1, *d_tw_n2, *d_tw_big, *d_tw_row_bwd, *d_tw_row_fwd, *d_tw_256;
+    int col_chunks;             // x pass of a stage is issued in this many column chunks (Infinity-Cache reuse)
     int nct_active;             // local column tiles that contain at least one unmasked ky (the rest is frozen forever)
     bool nyq_frozen;            // the ky = ny/2 column lies outside the dealiasing circle (always on square grids)
     cf *d_scratch;              // nx*P complex, lazily allocated (standalone r2c / c2r)
@@ -195,6 +196,8 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
         int act = (jmax - c->ky0 + 15) / 16;
         c->nct_active = act < 0 ? 0 : (act > c->P / 16 ? c->P / 16 : act);
         if (getenv("FB_NO_COLUMN_SKIP")) c->nct_active = c->P / 16;
+        c->col_chunks = 1;
+        if (const char *e = getenv("FB_COL_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 16) c->col_chunks = v; }
     }
     int rc;
     if ((rc = upload(&c->d_gx, c->h_gx)) || (rc = upload(&c->d_kx2, c->h_kx2)) ||
@@ -561,7 +564,9 @@ struct fb_model {
     cf *znyq;
     float *src;                      // vort_src or NULL (== zeros)
     cf *nat[3];                      // natural-layout temporaries for the record path (lazy)
-    bool primed;                     // W4 holds the block-backward derivatives of ZA
+    // 0: derivative fields stale; 1: W4 holds the derivatives with the backward x pass finished on the frozen
+    // tiles only (phase flow: FB_PH_COL_BWD comes next); 2: finished on every tile (ready for the row pass)
+    int primed;
 };
 
 static int model_create_impl(fb_model **out, fb_ctx *c, float nu, float dt, bool own)
@@ -662,7 +667,7 @@ extern "C" int fb_model_set_vort(fb_model *m, const float *d_vort)
     NEED_SINGLE(c);
     cf *dst = m->ZB;                                        // 3-pass row layout in ZB (stage scratch), then into ZA's layout
     HIPCHK(hipMemsetAsync(dst, 0, priv_elems(c) * sizeof(cf), c->stream));
-    m->primed = false;
+    m->primed = 0;
     int rc = r2c_private(c, d_vort, dst);                   // main.cpp:256
     if (rc) return rc;
     if (m->full) return full_import_state(m, dst);
@@ -717,7 +722,7 @@ static int full_import_state(fb_model *m, cf *spec3)
     const int ntiles = (c->ny / 2) / 8;
     hipLaunchKernelGGL((k_full_relayout<true>), dim3(c->max_wg), dim3(256), 0, c->stream, (const cf *)spec3, m->ZA, c->P, c->N1, c->N2, ntiles);
     HIPCHK(hipGetLastError());
-    m->primed = true;
+    m->primed = 2;
     return FB_OK;
 }
 
@@ -758,8 +763,15 @@ static int model_prime(fb_model *m)
     fb_ctx *c = m->c;
     int rc;
     if ((rc = launch_col_mid(c, mid_args(m, -1)))) return rc;
-    m->primed = true;
+    m->primed = 1;
     return launch_col_strided<+1>(c, m->w4_send, 4, w4_fstride(c), rowmap_w4(c), c->nct_active, c->P / 16 - c->nct_active);
+}
+// backward strided sub-pass on the active tiles: the phase flow's FB_PH_COL_BWD, or the fused flow's
+// catch-up right after priming (its stage loop starts with the row pass)
+static int model_col_bwd_active(fb_model *m)
+{
+    fb_ctx *c = m->c;
+    return launch_col_strided<+1>(c, m->w4_send, 4, w4_fstride(c), rowmap_w4(c), 0, c->nct_active);
 }
 
 // optional per-launch HIP-event profiler (bench.py's roofline leg)
@@ -782,6 +794,7 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
     if (nsteps == 0) return FB_OK;
     if (m->full && !m->primed) return fail(FB_EINVAL, "fb_model_step: set the state first");
     if (!m->primed && (rc = model_prime(m))) return rc;
+    if (m->primed == 1 && !m->full) { if ((rc = model_col_bwd_active(m))) return rc; m->primed = 2; }
     const float scale = 1.0f / (float)((size_t)c->nx * c->ny);
     for (int s = 0; s < nsteps; ++s) {
         for (int k = 0; k < 4; ++k) {
@@ -796,20 +809,29 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
                 PROF_END(3);
                 continue;
             }
-            PROF_BEGIN(0);
-            if ((rc = launch_col_strided<+1>(c, m->w4_send, 4, (long)priv_elems(c), rowmap_natural(), 0, c->nct_active))) return rc;
-            PROF_END(0);
+            // row pass on the derivative fields left by the previous stage (or the priming pass) ...
             RowArgs a = row_args_base(c);
             a.M = m->w4_recv; a.m_fstride = (long)priv_elems(c); a.T = m->t_send; a.src = m->src; a.scale = scale;
             PROF_BEGIN(1);
             if ((rc = launch_row<ROW_FUSED>(c, a))) return rc;
             PROF_END(1);
-            PROF_BEGIN(2);
-            if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0, rowmap_natural(), 0, c->nct_active))) return rc;
-            PROF_END(2);
-            PROF_BEGIN(3);
-            if ((rc = launch_col_mid(c, mid_args(m, k)))) return rc;
-            PROF_END(3);
+            // ... then the x pass in column chunks, each chained forward -> update -> backward so that a
+            // chunk's derivative fields are still in the Infinity Cache when the backward sub-pass reads them
+            const int nchunk = c->col_chunks;
+            for (int h = 0; h < nchunk; ++h) {
+                const int ct0 = (int)((long)c->nct_active * h / nchunk), ct1 = (int)((long)c->nct_active * (h + 1) / nchunk);
+                if (ct1 == ct0) continue;
+                PROF_BEGIN(2);
+                if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0, rowmap_natural(), ct0, ct1 - ct0))) return rc;
+                PROF_END(2);
+                MidArgs ma = mid_args(m, k); ma.ct0 = ct0; ma.nct = ct1 - ct0;
+                PROF_BEGIN(3);
+                if ((rc = launch_col_mid(c, ma))) return rc;
+                PROF_END(3);
+                PROF_BEGIN(0);
+                if ((rc = launch_col_strided<+1>(c, m->w4_send, 4, (long)priv_elems(c), rowmap_natural(), ct0, ct1 - ct0))) return rc;
+                PROF_END(0);
+            }
         }
     }
     return FB_OK;
@@ -830,7 +852,9 @@ extern "C" int fb_model_phase(fb_model *m, int phase, int stage, const float *d_
     case FB_PH_PRIME:                                       // derivatives of vort_c -> w4_send (block sub-pass done)
         return model_prime(m);
     case FB_PH_COL_BWD:                                     // strided backward sub-pass on the 4 fields (in w4_send)
-        return launch_col_strided<+1>(c, m->w4_send, 4, w4_fstride(c), rowmap_w4(c), 0, c->nct_active);
+        if (m->primed != 1) return fail(FB_EINVAL, "FB_PH_COL_BWD without FB_PH_PRIME / FB_PH_COL_FWD before it");
+        m->primed = 2;
+        return model_col_bwd_active(m);
     case FB_PH_ROW: {                                       // w4_recv (row slabs) -> tendency rows in t_send
         RowArgs a = row_args_base(c);
         a.M = m->w4_recv; a.m_fstride = w4_fstride(c); a.T = m->t_send; a.src = m->src; a.scale = scale;
@@ -840,6 +864,7 @@ extern "C" int fb_model_phase(fb_model *m, int phase, int stage, const float *d_
     case FB_PH_COL_FWD:                                     // t_recv (column slab) -> forward x pass + RK update + derivatives
         if (stage < 0 || stage > 3) return fail(FB_EINVAL, "fb_model_phase: stage");
         if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0, rowmap_natural(), 0, c->nct_active))) return rc;
+        m->primed = 1;
         return launch_col_mid(c, mid_args(m, stage));
     case FB_PH_R2C_ROWS: {                                  // local real rows -> y-transformed rows in t_send
         if (!d_real_in) return fail(FB_EINVAL, "fb_model_phase: d_real_in NULL");
@@ -848,10 +873,9 @@ extern "C" int fb_model_phase(fb_model *m, int phase, int stage, const float *d_
     }
     case FB_PH_R2C_COLS:                                    // t_recv -> vort_c (private layout)
         if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0)) || (rc = launch_col_block<-1>(c, m->t_recv, 1, 0))) return rc;
-        m->primed = false;
+        m->primed = 0;
         return state_convert(c, m->t_recv, m->ZA, true);
     case FB_PH_C2R_COLS:                                    // copy of vort_c -> x-inverse-transformed columns in t_recv
-        m->primed = false;                                  // w4_send is clobbered
         // vort_c is staged in t_recv's buffer-sized scratch (field 0 region is destination-blocked in slab mode)
         if ((rc = state_convert(c, m->ZA, m->t_recv, false))) return rc;
         if ((rc = launch_col_block<+1>(c, m->t_recv, 1, 0))) return rc;
@@ -917,7 +941,7 @@ extern "C" int fb_model_set_spectrum(fb_model *m, const float *d_spec)
 {
     if (!m || !d_spec) return fail(FB_EINVAL, "fb_model_set_spectrum: NULL");
     NEED_SINGLE(m->c);
-    m->primed = false;
+    m->primed = 0;
     if (m->full) {
         int rc = relayout(m->c, (const cf *)d_spec, m->ZB, true);
         return rc ? rc : full_import_state(m, m->ZB);

@@ -162,7 +162,6 @@ class SlabModel:
         self._exchange_t(reverse=True)
         out = be.empty_real()
         be.phase(PH_C2R_ROWS, real_out=out)
-        self.primed = False
         return out
 
     def step(self, n=1):
