@@ -63,6 +63,24 @@ int fb_memcpy_h2d(fb_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);  /
 int fb_memcpy_d2h(fb_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);  /* synchronous */
 int fb_memset0(fb_ctx *ctx, void *d_dst, size_t bytes);
 
+/* Asynchronous record path (no reference counterpart: main.cpp:266-282 writes synchronously from its only
+ * thread).  Pinned host buffers, non-blocking streams and events as opaque handles, so that a C/C++ host can
+ * overlap the D2H copies and the file writes of a record step with the following RK4 steps:
+ *   compute stream: fb_model_get_vort/diag -> fb_event_record(e1, compute)
+ *   copy stream   : fb_stream_wait_event(copy, e1) -> fb_memcpy_d2h_async(copy, ...) -> fb_event_record(e2, copy)
+ *   writer thread : fb_event_synchronize(e2) -> fb_write_field(...)                (host/barotropic_main.cpp) */
+int fb_malloc_host(void **h_ptr, size_t bytes);
+int fb_free_host(void *h_ptr);
+int fb_stream_create(void **stream);                 /* hipStreamNonBlocking; pass to fb_set_stream */
+int fb_stream_destroy(void *stream);
+int fb_stream_synchronize(void *stream);
+int fb_event_create(void **event);
+int fb_event_destroy(void *event);
+int fb_event_record(void *event, void *stream);
+int fb_stream_wait_event(void *stream, void *event);
+int fb_event_synchronize(void *event);
+int fb_memcpy_d2h_async(void *stream, void *h_dst, const void *d_src, size_t bytes);
+
 /* ---------------------------------------------------------------------------------------
  * Spectral operators on device half spectra (nx*(ny/2+1) complex).  in == out is allowed
  * (main-shallow-water.cpp:327, invert_pres.cpp:148-150).

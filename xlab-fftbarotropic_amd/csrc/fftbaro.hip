@@ -284,6 +284,45 @@ extern "C" int fb_memset0(fb_ctx *c, void *d, size_t n)
     HIPCHK(hipMemsetAsync(d, 0, n, c->stream)); return FB_OK;
 }
 
+// ---- asynchronous record path: pinned host memory, streams, events (opaque void* handles) ----
+extern "C" int fb_malloc_host(void **p, size_t bytes)
+{
+    if (!p) return fail(FB_EINVAL, "fb_malloc_host: NULL");
+    hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) return fail(FB_ENOMEM, "hipHostMalloc: out of memory");
+    HIPCHK(e);
+    return FB_OK;
+}
+extern "C" int fb_free_host(void *p) { if (p) HIPCHK(hipHostFree(p)); return FB_OK; }
+extern "C" int fb_stream_create(void **stream)
+{
+    if (!stream) return fail(FB_EINVAL, "fb_stream_create: NULL");
+    hipStream_t s;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return FB_OK;
+}
+extern "C" int fb_stream_destroy(void *stream) { if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream)); return FB_OK; }
+extern "C" int fb_stream_synchronize(void *stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return FB_OK; }
+extern "C" int fb_event_create(void **ev)
+{
+    if (!ev) return fail(FB_EINVAL, "fb_event_create: NULL");
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *ev = (void *)e;
+    return FB_OK;
+}
+extern "C" int fb_event_destroy(void *ev) { if (ev) HIPCHK(hipEventDestroy((hipEvent_t)ev)); return FB_OK; }
+extern "C" int fb_event_record(void *ev, void *stream) { if (!ev) return fail(FB_EINVAL, "event NULL"); HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return FB_OK; }
+extern "C" int fb_stream_wait_event(void *stream, void *ev) { if (!ev) return fail(FB_EINVAL, "event NULL"); HIPCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0)); return FB_OK; }
+extern "C" int fb_event_synchronize(void *ev) { if (!ev) return fail(FB_EINVAL, "event NULL"); HIPCHK(hipEventSynchronize((hipEvent_t)ev)); return FB_OK; }
+extern "C" int fb_memcpy_d2h_async(void *stream, void *h_dst, const void *d_src, size_t bytes)
+{
+    if (!h_dst || !d_src) return fail(FB_EINVAL, "fb_memcpy_d2h_async: NULL");
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return FB_OK;
+}
+
 // --------------------------------------------------------------------------------------------
 // pointwise launches
 // --------------------------------------------------------------------------------------------

@@ -9,10 +9,13 @@
 #include <getopt.h>
 #include <unistd.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fftbaro.h"
@@ -53,6 +56,40 @@ struct VortSrcReader {
         return 0;
     }
     ~VortSrcReader() { if (fifo) fclose(fifo); }
+};
+
+// Record path off the critical path: the main thread enqueues the record kernels and the D2H copies and
+// goes on stepping; this thread waits for the copies and writes the files + ./log lines in the reference's order.
+struct RecordWriter {
+    std::thread th; std::mutex mu; std::condition_variable cv;
+    bool has_job = false, quit = false; int step = 0;
+    void *e_copy = nullptr; float *h[4] = {nullptr, nullptr, nullptr, nullptr}; std::vector<float> src_snapshot;
+    std::string output; FILE *log_fd = nullptr; size_t grids = 0;
+    void start() { th = std::thread([this] { run(); }); }
+    void run()
+    {
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [this] { return has_job || quit; });
+            if (!has_job && quit) return;
+            const int st = step;
+            lk.unlock();
+            must(fb_event_synchronize(e_copy), "record: wait for copies");
+            char fn[1024];
+            const char *names[5] = {"vort_src_input", "vort", "psi", "u", "v"};
+            for (int i = 0; i < 5; ++i) {                                              // main.cpp:268-278, :187-220
+                snprintf(fn, sizeof fn, "%s/%s_step_%d.bin", output.c_str(), names[i], st);
+                must(fb_write_field(fn, i == 0 ? src_snapshot.data() : h[i - 1], grids), "writeField");
+                fprintf(log_fd, "%s\n", fn); fflush(log_fd);
+            }
+            lk.lock();
+            has_job = false;
+            cv.notify_all();
+        }
+    }
+    void wait_idle() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return !has_job; }); }
+    void submit(int st) { { std::lock_guard<std::mutex> lk(mu); step = st; has_job = true; } cv.notify_all(); }
+    void stop() { wait_idle(); { std::lock_guard<std::mutex> lk(mu); quit = true; } cv.notify_all(); if (th.joinable()) th.join(); }
 };
 
 int main(int argc, char *args[])
@@ -104,12 +141,22 @@ int main(int argc, char *args[])
 
     fb_ctx *fop = nullptr; fb_model *model = nullptr;
     must(fb_create(&fop, XPTS, YPTS, LX, LY), "fb_create");
+    void *compute = nullptr, *copy = nullptr, *e_rec = nullptr, *e_copy = nullptr;
+    must(fb_stream_create(&compute), "stream"); must(fb_stream_create(&copy), "stream");
+    must(fb_event_create(&e_rec), "event"); must(fb_event_create(&e_copy), "event");
+    must(fb_set_stream(fop, compute), "fb_set_stream");
     must(fb_model_create(&model, fop, NU, dt), "fb_model_create");
-    float *d_field = nullptr, *d_psi = nullptr, *d_u = nullptr, *d_v = nullptr;
+    float *d_field = nullptr, *d_vort = nullptr, *d_psi = nullptr, *d_u = nullptr, *d_v = nullptr;
     must(fb_malloc((void **)&d_field, GRIDS * sizeof(float)), "fb_malloc");
+    must(fb_malloc((void **)&d_vort, GRIDS * sizeof(float)), "fb_malloc");
     must(fb_malloc((void **)&d_psi, GRIDS * sizeof(float)), "fb_malloc");
     must(fb_malloc((void **)&d_u, GRIDS * sizeof(float)), "fb_malloc");
     must(fb_malloc((void **)&d_v, GRIDS * sizeof(float)), "fb_malloc");
+    RecordWriter writer;
+    for (int i = 0; i < 4; ++i) must(fb_malloc_host((void **)&writer.h[i], GRIDS * sizeof(float)), "fb_malloc_host");
+    writer.e_copy = e_copy; writer.output = output; writer.log_fd = log_fd; writer.grids = GRIDS; writer.src_snapshot.assign(GRIDS, 0.0f);
+    writer.start();
+    bool copies_pending = false;
     std::vector<float> host(GRIDS), vort_src(GRIDS, 0.0f);                           // vort_src defined as zeros (main.cpp:110 leaves it uninitialised)
     char filename[1024];
 
@@ -121,13 +168,6 @@ int main(int argc, char *args[])
     printf("Initialization complete.\n");
     must(fb_model_set_vort(model, d_field), "fb_model_set_vort");                     // main.cpp:256
 
-    auto dump = [&](const char *name, int step, float *dev) {
-        snprintf(filename, sizeof filename, "%s/%s_step_%d.bin", output.c_str(), name, step);
-        if (dev) must(fb_memcpy_d2h(fop, host.data(), dev, GRIDS * sizeof(float)), "d2h");
-        must(fb_write_field(filename, dev ? host.data() : vort_src.data(), GRIDS), "writeField");
-        fprintf(log_fd, "%s\n", filename); fflush(log_fd);
-    };
-
     int record_flag = 0;
     // The reference can be restarted from any vort_step_N.bin via -i, but always renumbers from 0
     // (SURVEY section 5); --start-step N continues the numbering and the source clock instead.
@@ -136,9 +176,18 @@ int main(int argc, char *args[])
         if ((record_flag = ((step % record_step) == 0))) printf(", record now!");
         printf("\n");
         if (record_flag) {                                                             // main.cpp:266-282 and the stage-0 dumps :181-222
-            dump("vort_src_input", step, nullptr);
-            must(fb_model_get_vort(model, d_field), "fb_model_get_vort");
-            dump("vort", step, d_field);
+            writer.wait_idle();                                                        // pinned buffers and the snapshot are free again
+            if (copies_pending) must(fb_stream_wait_event(compute, e_copy), "wait");  // device record buffers are free again
+            writer.src_snapshot = vort_src;                                            // vort_src as of this step (dumped BEFORE this step's read)
+            must(fb_model_get_vort(model, d_vort), "fb_model_get_vort");
+            must(fb_model_get_diag(model, d_psi, d_u, d_v), "fb_model_get_diag");      // functions of vort_c only: the reference's stage-0 values
+            must(fb_event_record(e_rec, compute), "record");
+            must(fb_stream_wait_event(copy, e_rec), "wait");
+            float *dev[4] = {d_vort, d_psi, d_u, d_v};
+            for (int i = 0; i < 4; ++i) must(fb_memcpy_d2h_async(copy, writer.h[i], dev[i], GRIDS * sizeof(float)), "d2h");
+            must(fb_event_record(e_copy, copy), "record");
+            copies_pending = true;
+            writer.submit(step);
         }
         if (recipe_type != EMPTY) {                                                    // main-shallow-water.cpp:304
             vs_reader.read(step * dt);
@@ -149,16 +198,15 @@ int main(int argc, char *args[])
                 vs_reader.fresh = false;
             }
         }
-        if (record_flag) {                        // psi/u/v are functions of vort_c only: same values as the reference's stage-0 dumps
-            must(fb_model_get_diag(model, d_psi, d_u, d_v), "fb_model_get_diag");
-            dump("psi", step, d_psi); dump("u", step, d_u); dump("v", step, d_v);
-        }
         must(fb_model_step(model, 1), "fb_model_step");                                // main.cpp:286-317
     }
+    writer.stop();
     must(fb_synchronize(fop), "sync");
     fclose(log_fd);
-    fb_free(d_field); fb_free(d_psi); fb_free(d_u); fb_free(d_v);
+    fb_free(d_field); fb_free(d_vort); fb_free(d_psi); fb_free(d_u); fb_free(d_v);
+    for (int i = 0; i < 4; ++i) fb_free_host(writer.h[i]);
     fb_model_destroy(model); fb_destroy(fop);
+    fb_event_destroy(e_rec); fb_event_destroy(e_copy); fb_stream_destroy(copy); fb_stream_destroy(compute);
     printf("Program ends. Congrats!\n");
     return 0;
 }
