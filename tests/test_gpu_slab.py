@@ -100,6 +100,15 @@ def test_slab_model_world1_api():
     assert np.array_equal(m.vort_local().cpu().numpy().view(np.uint32), ref.vort().cpu().numpy().view(np.uint32))
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def test_bench_two_ranks_on_one_gpu_gloo(tmp_path):
     """The real multi-process flow of bench.py (torch.distributed.run, SlabModel + HipBackend, exchange
     between phases) with 2 ranks sharing the GPU over gloo -- RCCL itself needs two devices."""
@@ -109,7 +118,7 @@ def test_bench_two_ranks_on_one_gpu_gloo(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--grid", "512", "--backend", "gloo", "--cpu-steps", "0"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -138,7 +147,7 @@ def test_slab_model_two_ranks_gloo_matches_single(tmp_path):
         "np.save(os.path.join(%r, 'rows%%d.npy' %% r), m.vort_local().cpu().numpy())\n"
         "dist.destroy_process_group()\n" % (root, str(tmp_path)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29618", str(script)]
+           "--master-port", str(_free_port()), str(script)]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     import xlab_fftbarotropic_amd as X

@@ -402,7 +402,8 @@ template <int N, int MODE> static int launch_row_t(fb_ctx *c, const RowArgs &a)
     using C = RowCfg<N>;
     const int npairs = a.nx / 2;
     int grid = (npairs + C::G - 1) / C::G;
-    const int cap = c->max_wg / 2;            // ~4 resident workgroups per CU
+    int cap = c->max_wg / 2;                  // persistent-style grid: a few workgroups per CU, each loops over row pairs
+    if (const char *e = getenv("FB_ROW_GRID")) { int v = atoi(e); if (v >= 64) cap = v; }
     if (grid > cap) grid = cap;
     const bool slab = a.m_sstride != 0 || a.t_sstride != 0;
     auto kern = slab ? k_row<N, MODE, true> : k_row<N, MODE, false>;
