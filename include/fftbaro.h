@@ -135,6 +135,9 @@ int fb_model_set_vort(fb_model *m, const float *d_vort_real);
  * VortSrcRecipeReader::read in main-shallow-water.cpp:304 */
 int fb_model_set_source(fb_model *m, const float *d_src_real);
 int fb_model_step(fb_model *m, int nsteps);
+/* enable != 0: fb_model_step replays one captured RK4 step as a hipGraph (16 kernel launches per step are
+ * launch-bound on small grids).  Needs a non-null context stream (fb_set_stream); otherwise steps run eagerly. */
+int fb_model_use_graph(fb_model *m, int enable);
 /* record path: c2r of a copy of vort_c + normalise   main.cpp:273-281 */
 int fb_model_get_vort(fb_model *m, float *d_vort_real);
 /* stage-0 record dumps psi, u, v (any may be NULL)   main.cpp:181-222 */

@@ -316,3 +316,54 @@ def test_experimental_single_pass_x_transform(O, R):
             outs[flag] = (np.load(a), np.load(b))
     assert R.rel_l2(outs["1"][0], outs["0"][0]) < 2e-6          # same maths, different FFT factorisation
     assert R.rel_l2(outs["1"][1].view(np.float32), outs["0"][1].view(np.float32)) < 2e-6
+
+
+def test_graph_replay_matches_eager(X, torch):
+    """fb_model_use_graph: the captured RK4 step replayed as a hipGraph gives bit-identical fields,
+    including across a source change (which invalidates the captured kernel arguments)."""
+    n = 256
+    v0 = X.make_field("elliptic", n)
+    src = X.make_source_kuo2004(n)
+    ref = X.Model(n, n)
+    ref.set_vort(v0)
+    ref.step(7)
+    ref.set_source(src)
+    ref.step(6)
+    want = ref.vort().cpu().numpy()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        m = X.Model(n, n)
+        m.fop.use_current_stream()
+        m.use_graph(True)
+        m.set_vort(v0)
+        m.step(7)
+        m.set_source(src)
+        m.step(6)
+        got = m.vort().cpu().numpy()
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+def test_api_edge_cases(X, torch):
+    """Misuse and degenerate calls: zero steps, stepping an all-zero state, source toggling, phase order."""
+    import ctypes as C
+    L_ = X.lib()
+    n = 64                                             # smallest supported grid
+    m = X.Model(n, n)
+    m.step(0)
+    assert L_.fb_model_step(m._h, -1) == 1             # FB_EINVAL
+    m.step(2)                                          # never initialised: vort_c = 0 stays 0
+    assert float(m.vort().abs().max()) == 0.0
+    m.set_source(None)
+    m.set_source(None)
+    z = torch.zeros((n, n), dtype=torch.float32, device="cuda")
+    m.set_source(z)
+    m.step(1)
+    assert float(m.vort().abs().max()) == 0.0
+    assert L_.fb_model_phase(m._h, 1, 0, None, None) == 1     # FB_PH_COL_BWD without a PRIME/COL_FWD before it
+    assert L_.fb_model_phase(m._h, 99, 0, None, None) == 1
+    assert L_.fb_model_phase(m._h, 4, 0, None, None) == 1     # R2C_ROWS without input
+    h = C.c_void_p()
+    assert L_.fb_create_slab(C.byref(h), 256, 256, 6e5, 6e5, 3, 2) == 1   # rank out of range
+    assert L_.fb_create_slab(C.byref(h), 256, 256, 6e5, 6e5, 0, 3) == 1   # world not a power of two
+    assert L_.fb_create(C.byref(h), 32, 32, 6e5, 6e5) == 5                # below the minimum size
+    assert L_.fb_create(C.byref(h), 32768, 64, 6e5, 6e5) == 5             # above the maximum size

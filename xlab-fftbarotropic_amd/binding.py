@@ -70,6 +70,7 @@ def lib():
     L.fb_model_set_vort.argtypes = [vp, fp]
     L.fb_model_set_source.argtypes = [vp, fp]
     L.fb_model_step.argtypes = [vp, ip]
+    L.fb_model_use_graph.argtypes = [vp, ip]
     L.fb_model_get_vort.argtypes = [vp, fp]
     L.fb_model_get_diag.argtypes = [vp, fp, fp, fp]
     L.fb_model_get_spectrum.argtypes = [vp, fp]
@@ -95,7 +96,7 @@ EXPORTS = [
     "fb_gradx", "fb_grady", "fb_laplacian", "fb_invert_laplacian", "fb_dealiase", "fb_r2c", "fb_c2r",
     "fb_backward_normalize", "fb_negate", "fb_jacobian", "fb_spec_axpy", "fb_spec_evolve", "fb_spec_rk4_combine",
     "fb_model_create", "fb_model_destroy", "fb_model_set_vort", "fb_model_set_source", "fb_model_step",
-    "fb_model_get_vort", "fb_model_get_diag", "fb_model_get_spectrum", "fb_model_set_spectrum", "fb_model_info",
+    "fb_model_use_graph", "fb_model_get_vort", "fb_model_get_diag", "fb_model_get_spectrum", "fb_model_set_spectrum", "fb_model_info",
     "fb_model_time_steps", "fb_model_profile_steps", "fb_write_field", "fb_read_field", "fb_make_field", "fb_make_source_kuo2004",
     "fb_create_slab", "fb_slab_geometry", "fb_model_create_slab", "fb_model_phase",
     "fb_malloc_host", "fb_free_host", "fb_stream_create", "fb_stream_destroy", "fb_stream_synchronize", "fb_event_create",
@@ -268,6 +269,10 @@ class Model:
             a = self._dev(src); check(lib().fb_model_set_source(self._h, _ptr(a))); self.fop.synchronize()
 
     def step(self, n=1): check(lib().fb_model_step(self._h, n))
+
+    def use_graph(self, enable=True):
+        """hipGraph replay of the step; call under a non-default torch stream (after fop.use_current_stream())."""
+        check(lib().fb_model_use_graph(self._h, 1 if enable else 0))
 
     def time_steps(self, n):
         ms = C.c_float()

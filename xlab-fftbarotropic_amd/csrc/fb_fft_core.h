@@ -61,13 +61,16 @@ template <int DIR> struct Bfly<8, DIR> {
     static FB_DEV void run(cf *v)
     {
         fft4<DIR>(v[0], v[2], v[4], v[6]);            // even  -> E[k] in v[0],v[2],v[4],v[6]
+        __builtin_amdgcn_sched_barrier(0);
         fft4<DIR>(v[1], v[3], v[5], v[7]);            // odd   -> O[k] in v[1],v[3],v[5],v[7]
+        __builtin_amdgcn_sched_barrier(0);
         cf o1 = mul_w16<2, DIR>(v[3]), o2 = mul_w16<4, DIR>(v[5]), o3 = mul_w16<6, DIR>(v[7]);
         cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
         v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
         v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
         v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
         v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+        __builtin_amdgcn_sched_barrier(0);
     }
 };
 // scheduling fence: the four independent radix-4 sub-butterflies of a radix-16 are NOT interleaved

@@ -238,7 +238,7 @@ template <int N, bool SLAB>
 FB_DEV void row_dma_issue(cf *stg, int t, const cf *baseA, const cf *baseB, int rowA, int rowB, int ks, long sstride,
                           cf &nyqA, cf &nyqB)
 {
-    constexpr int T = N / 16, NW = T / 64, CH = N / 256;         // waves per group, 1-KiB chunks per row
+    constexpr int T = N / 16, NW = T >= 64 ? T / 64 : 1, CH = N / 256;   // waves per group, 1-KiB chunks per row (only used when T >= 64)
     const int w = t >> 6, lane = t & 63;
 #pragma unroll
     for (int c = 0; c < CH / NW; ++c) {

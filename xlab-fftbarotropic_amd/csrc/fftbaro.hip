@@ -602,6 +602,11 @@ struct fb_model {
     // the frozen ky = ny/2 column of vort_c is kept in znyq[nx] (natural kx order)
     bool full;
     cf *znyq;
+    // hipGraph replay of one RK4 step (launch-bound small grids): captured lazily on a non-null stream,
+    // dropped whenever something baked into the kernel arguments changes (source pointer, stream)
+    bool use_graph, warmed;
+    hipGraphExec_t graph_exec;
+    const float *graph_src; hipStream_t graph_stream;
     float *src;                      // vort_src or NULL (== zeros)
     cf *nat[3];                      // natural-layout temporaries for the record path (lazy)
     // 0: derivative fields stale; 1: W4 holds the derivatives with the backward x pass finished on the frozen
@@ -675,11 +680,14 @@ extern "C" int fb_slab_geometry(fb_ctx *c, int *rows_local, int *cols_per_slab, 
     return FB_OK;
 }
 
+static void model_drop_graph(fb_model *m);
+
 extern "C" int fb_model_destroy(fb_model *m)
 {
     if (!m) return FB_OK;
     hipFree(m->ZA); hipFree(m->ZB); hipFree(m->ACC);
     if (m->znyq) hipFree(m->znyq);
+    model_drop_graph(m);
     if (m->own_buffers) { hipFree(m->TT); hipFree(m->W4); }
     if (m->src) hipFree(m->src);
     for (auto p : m->nat) if (p) hipFree(p);
@@ -705,6 +713,7 @@ extern "C" int fb_model_set_vort(fb_model *m, const float *d_vort)
     if (!m || !d_vort) return fail(FB_EINVAL, "fb_model_set_vort: NULL");
     fb_ctx *c = m->c;
     NEED_SINGLE(c);
+    m->warmed = false;                                      // the next fb_model_step starts with an eager (priming) step
     cf *dst = m->ZB;                                        // 3-pass row layout in ZB (stage scratch), then into ZA's layout
     HIPCHK(hipMemsetAsync(dst, 0, priv_elems(c) * sizeof(cf), c->stream));
     m->primed = 0;
@@ -877,7 +886,45 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
     return FB_OK;
 }
 
-extern "C" int fb_model_step(fb_model *m, int nsteps) { return model_step_impl(m, nsteps, nullptr); }
+static void model_drop_graph(fb_model *m)
+{
+    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+}
+
+extern "C" int fb_model_use_graph(fb_model *m, int enable)
+{
+    if (!m) return fail(FB_EINVAL, "model NULL");
+    m->use_graph = enable != 0;
+    if (!m->use_graph) model_drop_graph(m);
+    return FB_OK;
+}
+
+extern "C" int fb_model_step(fb_model *m, int nsteps)
+{
+    if (!m || nsteps < 0) return fail(FB_EINVAL, "fb_model_step: bad argument");
+    fb_ctx *c = m->c;
+    // graph replay needs a capturable (non-null) stream, a primed pipeline and at least one eager step behind
+    // us (kernel attributes are set on first launch); anything else runs eagerly
+    if (!m->use_graph || c->world != 1 || c->stream == nullptr || nsteps < 2) { if (nsteps > 0) m->warmed = true; return model_step_impl(m, nsteps, nullptr); }
+    int rc;
+    if (!m->warmed) { if ((rc = model_step_impl(m, 1, nullptr))) return rc; m->warmed = true; --nsteps; }
+    if (m->graph_exec && (m->graph_src != m->src || m->graph_stream != c->stream)) model_drop_graph(m);
+    if (!m->graph_exec) {
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        rc = model_step_impl(m, 1, nullptr);
+        hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        HIPCHK(e);
+        e = hipGraphInstantiate(&m->graph_exec, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        HIPCHK(e);
+        m->graph_src = m->src; m->graph_stream = c->stream;
+        // the captured step has NOT executed: replay it below like the others
+    }
+    for (int s = 0; s < nsteps; ++s) HIPCHK(hipGraphLaunch(m->graph_exec, c->stream));
+    return FB_OK;
+}
 
 // One phase of the slab-decomposed step; the caller performs the all-to-all transposes between
 // phases (see include/fftbaro.h).  Valid for world == 1 too (then no exchange is needed).
@@ -982,6 +1029,7 @@ extern "C" int fb_model_set_spectrum(fb_model *m, const float *d_spec)
     if (!m || !d_spec) return fail(FB_EINVAL, "fb_model_set_spectrum: NULL");
     NEED_SINGLE(m->c);
     m->primed = 0;
+    m->warmed = false;
     if (m->full) {
         int rc = relayout(m->c, (const cf *)d_spec, m->ZB, true);
         return rc ? rc : full_import_state(m, m->ZB);
