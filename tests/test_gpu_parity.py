@@ -367,3 +367,24 @@ def test_api_edge_cases(X, torch):
     assert L_.fb_create_slab(C.byref(h), 256, 256, 6e5, 6e5, 0, 3) == 1   # world not a power of two
     assert L_.fb_create(C.byref(h), 32, 32, 6e5, 6e5) == 5                # below the minimum size
     assert L_.fb_create(C.byref(h), 32768, 64, 6e5, 6e5) == 5             # above the maximum size
+
+
+def test_config3_1000_steps_stay_physical(X):
+    """BASELINE.json configs[2]: 4096^2 Kuo2004, dt = 3*1024/4096 s, 1000 RK4 steps on the GPU (the oracle
+    would need over an hour): size-independent properties only -- finite, mean vorticity conserved
+    exactly, enstrophy non-increasing, maximum principle roughly kept."""
+    n = 4096
+    v0 = X.make_field("kuo2004", n)
+    m = X.Model(n, n, dt=0.75)
+    m.set_vort(v0)
+    s0 = m.spectrum()[0, 0].item()
+    e_prev = float((m.vort().double() ** 2).sum())
+    for _ in range(4):
+        m.step(250)
+        v = m.vort()
+        assert bool(v.isfinite().all())
+        e = float((v.double() ** 2).sum())
+        assert e <= e_prev * (1 + 1e-6)
+        e_prev = e
+    assert m.spectrum()[0, 0].item() == s0
+    assert float(v.max()) < 1.05 * float(v0.max()) and float(v.min()) > -0.05 * float(v0.max())
