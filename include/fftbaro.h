@@ -33,7 +33,8 @@ extern "C" {
 const char *fb_strerror(int status);
 const char *fb_last_error(void);          /* thread-local detail of the last failure */
 int fb_version(void);                      /* 100*major + minor                       */
-/* 1 if (nx,ny) is supported: powers of two, 64 <= n <= 16384 */
+/* 1 if (nx,ny) is supported: each a power of two in [64, 16384] or 3*2^k in [192, 3072]
+ * (the reference's default NPTS = 768, configuration.hpp:18) */
 int fb_size_supported(int nx, int ny);
 
 /* ---------------------------------------------------------------------------------------

@@ -39,7 +39,8 @@ def test_no_gpu_means_loud_failure():
     assert b"no CPU fallback" in L.fb_last_error()
     with pytest.raises(X.FftBaroError):
         X.Model(256)
-    assert L.fb_size_supported(4096, 4096) == 1 and L.fb_size_supported(768, 768) == 0
+    assert L.fb_size_supported(4096, 4096) == 1 and L.fb_size_supported(768, 768) == 1
+    assert L.fb_size_supported(1000, 1000) == 0 and L.fb_size_supported(768, 4096) == 1 and L.fb_size_supported(6144, 64) == 0
     assert L.fb_strerror(5) == b"unsupported grid size"
 
 

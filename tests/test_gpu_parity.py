@@ -48,7 +48,7 @@ def _bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-@pytest.mark.parametrize("nx,ny", [(64, 64), (256, 256), (128, 64), (64, 256)])
+@pytest.mark.parametrize("nx,ny", [(64, 64), (256, 256), (128, 64), (64, 256), (768, 768), (192, 384)])
 def test_tables_bit_exact(X, O, nx, ny):
     fop = X.FftwfOperation(nx, ny, L, L)
     got = fop.tables()
@@ -108,7 +108,9 @@ def test_pointwise_sweeps_bit_exact(X, torch):
 
 
 @pytest.mark.parametrize("nx,ny", [(64, 64), (128, 64), (64, 128), (256, 256), (512, 512), (1024, 1024),
-                                   (2048, 2048), (4096, 4096)])
+                                   (2048, 2048), (4096, 4096),
+                                   # 3*2^k grids (radix-3 row kernel k_row3, 24-row strided column tiles)
+                                   (768, 768), (192, 192), (384, 256), (256, 1536), (3072, 192), (1536, 3072)])
 def test_r2c_c2r_vs_oracle(X, O, R, torch, nx, ny):
     fop = X.FftwfOperation(nx, ny, L, L)
     rng = np.random.default_rng(nx * 3 + ny)
@@ -150,7 +152,9 @@ def test_model_golden_64(X, R):
         assert R.rel_l2(m.vort().cpu().numpy(), G["fp64_vort_step%d" % upto]) < 1e-5, upto
 
 
-@pytest.mark.parametrize("n,kind,steps", [(256, "elliptic", 100), (128, "gaussian", 50), (512, "kuo2004", 20)])
+@pytest.mark.parametrize("n,kind,steps", [(256, "elliptic", 100), (128, "gaussian", 50), (512, "kuo2004", 20),
+                                          (768, "elliptic", 100),        # the reference's shipped default grid (configuration.hpp:18)
+                                          (192, "gaussian", 30), (1536, "kuo2004", 5)])
 def test_model_vs_oracle(X, O, R, n, kind, steps):
     v0 = O.make_field(kind, n)
     m = X.Model(n, n)
@@ -171,7 +175,8 @@ def test_model_vs_oracle(X, O, R, n, kind, steps):
     assert np.array_equal(_bits(m2.vort().cpu().numpy()), _bits(m.vort().cpu().numpy()))
 
 
-@pytest.mark.parametrize("nx,ny", [(128, 256), (256, 8192), (128, 16384), (8192, 128), (16384, 64), (2048, 512)])
+@pytest.mark.parametrize("nx,ny", [(128, 256), (256, 8192), (128, 16384), (8192, 128), (16384, 64), (2048, 512),
+                                   (384, 128), (128, 768), (3072, 64)])
 def test_model_nonsquare(X, O, R, nx, ny):
     """Also the cheap way to exercise the long-row kernels (ny = 8192, 16384: LDS-DMA path / 1024-thread
     groups) and the long-column kernels (nx = 8192, 16384: 128-row wave tiles) against the oracle."""
@@ -244,7 +249,8 @@ def test_errors(X):
     import ctypes as C
     Lb = X.lib()
     h = C.c_void_p()
-    assert Lb.fb_create(C.byref(h), 768, 768, L, L) == 5          # FB_EUNSUPPORTED (non power of two)
+    assert Lb.fb_create(C.byref(h), 1000, 1000, L, L) == 5        # FB_EUNSUPPORTED (not 2^k or 3*2^k)
+    assert Lb.fb_create(C.byref(h), 6144, 6144, L, L) == 5        # 3*2^k beyond 3072
     assert Lb.fb_create(C.byref(h), 256, 256, -1.0, L) == 1       # FB_EINVAL
     assert Lb.fb_gradx(None, None, None) == 1
     with pytest.raises(X.FftBaroError):

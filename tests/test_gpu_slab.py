@@ -40,7 +40,7 @@ class _Group:
             b.phase(ph, **kw)
 
 
-@pytest.mark.parametrize("world,n,steps", [(1, 256, 3), (2, 256, 3), (4, 256, 2), (8, 512, 1), (2, 1024, 2)])
+@pytest.mark.parametrize("world,n,steps", [(1, 256, 3), (2, 256, 3), (4, 256, 2), (8, 512, 1), (2, 1024, 2), (4, 768, 2)])
 def test_slab_phases_match_fused_path(world, n, steps):
     import torch
     from importlib import import_module

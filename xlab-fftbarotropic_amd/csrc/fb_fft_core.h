@@ -57,6 +57,17 @@ template <int R, int DIR> struct Bfly;
 template <int DIR> struct Bfly<1, DIR> { static FB_DEV void run(cf *) {} };
 template <int DIR> struct Bfly<2, DIR> { static FB_DEV void run(cf *v) { fft2<DIR>(v[0], v[1]); } };
 template <int DIR> struct Bfly<4, DIR> { static FB_DEV void run(cf *v) { fft4<DIR>(v[0], v[1], v[2], v[3]); } };
+// radix 3 (grids 3*2^k, e.g. the reference's default NPTS = 768): W3 = exp(-+2 pi i/3) = (-1/2, -+sqrt(3)/2)
+#define FB_SQRT3_2 0.86602540378443864676f
+template <int DIR> FB_DEV void fft3(cf &a0, cf &a1, cf &a2)
+{
+    const cf s = cadd(a1, a2), d = csub(a1, a2);
+    const cf m = cf_make(a0.x - 0.5f * s.x, a0.y - 0.5f * s.y);
+    // forward: -i*(sqrt3/2)*d ; backward: +i*(sqrt3/2)*d
+    const cf r = DIR < 0 ? cf_make(FB_SQRT3_2 * d.y, -FB_SQRT3_2 * d.x) : cf_make(-FB_SQRT3_2 * d.y, FB_SQRT3_2 * d.x);
+    a0 = cadd(a0, s); a1 = cadd(m, r); a2 = csub(m, r);
+}
+template <int DIR> struct Bfly<3, DIR> { static FB_DEV void run(cf *v) { fft3<DIR>(v[0], v[1], v[2]); } };
 template <int DIR> struct Bfly<8, DIR> {
     static FB_DEV void run(cf *v)
     {

@@ -398,7 +398,12 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
 // fields are laid out [dst rank][field][local row][KS] so that ONE all-to-all moves all of them.
 struct RowMap {
     int xl_shift, xl_mask; long dstride;
-    FB_DEV size_t off(int r, int P) const { return (size_t)(r >> xl_shift) * dstride + (size_t)(r & xl_mask) * P; }
+    int xl;            // rows per destination block when it is not a power of two (3*2^k grids), else 0
+    FB_DEV size_t off(int r, int P) const
+    {
+        if (xl) { const int d = r / xl; return (size_t)d * dstride + (size_t)(r - d * xl) * P; }
+        return (size_t)(r >> xl_shift) * dstride + (size_t)(r & xl_mask) * P;
+    }
 };
 
 struct ColArgs {

@@ -1,0 +1,164 @@
+// fb_row3.h -- row pass for ny = 3*M (M a power of two): the reference's shipped default grid is
+// NPTS = 768 = 3*2^8 (configuration.hpp:18).
+//
+// A length-3M complex transform is one radix-3 step plus three length-M transforms, which are the
+// power-of-two workgroup FFTs of fb_fft_core.h run by three thread groups side by side:
+//   backward (c2r): G_r[k0] = W_N^{-r k0} * sum_j W_3^{-r j} Z[k0 + M j]     (radix-3 on the input thirds)
+//                   z[3m + r] = IFFT_M(G_r)[m]                               (group r, r = 0,1,2)
+//   forward  (r2c): F_r = FFT_M(z[3m + r]);  Z[k0 + M j] = sum_r W_3^{r j} W_N^{r k0} F_r[k0]
+// Same packing as k_row: two real-output transforms per complex backward FFT (Hermitian extension
+// with the reference's c2r semantics, SURVEY note N2), two x rows per forward FFT, untangle on store.
+// Correctness-first (plain global loads, no LDS-DMA): these grids are not benchmark configurations.
+#pragma once
+#include "fb_kernels.h"
+
+template <int M> struct Row3Cfg {
+    static constexpr int N = 3 * M, T = M / 16, PT = 3 * T;
+    static constexpr int THREADS = 192;
+    static constexpr int GP = THREADS / PT;                 // row pairs per workgroup
+    static constexpr int LSTR = M + M / 16;                 // padded complex per sub-transform buffer
+    static constexpr bool SHARE = RowPlanSymmetric<M>::value;
+    static constexpr int TWL_B = RowTwSrc<M, false, true>::LDS_CF, TWL_F = SHARE ? 0 : RowTwSrc<M, true, true>::LDS_CF;
+    static constexpr size_t LDS_BYTES = ((size_t)GP * 3 * LSTR + TWL_B + TWL_F) * sizeof(cf);
+};
+
+// Hermitian-extended packed spectrum value Z[k], 0 <= k < N, of the two half-spectrum rows A, B
+template <int N, bool SLAB>
+FB_DEV cf row3_z(const cf *baseA, const cf *baseB, int rowA, int rowB, int ks, long sstride, int k)
+{
+    const bool mirror = 2 * k > N;
+    const int kk = mirror ? N - k : k;
+    const cf a = *row_ptr<SLAB>(baseA, ks, sstride, rowA, kk), b = *row_ptr<SLAB>(baseB, ks, sstride, rowB, kk);
+    if (kk == 0 || 2 * kk == N) return cf_make(a.x, b.x);                     // Im ignored at k = 0 and k = N/2
+    return mirror ? cf_make(a.x + b.y, b.x - a.y) : cf_make(a.x - b.y, a.y + b.x);
+}
+
+// backward input of sub-transform r: radix-3 over the spectrum thirds + twiddle, into the first stage's registers
+template <int M, bool SLAB>
+FB_DEV void row3_load(cf *reg, int r, int t, const cf *baseA, const cf *baseB, int rowA, int rowB, int ks, long sstride,
+                      const cf *__restrict__ twN)
+{
+    constexpr int N = 3 * M, T = M / 16, R0 = RowTw<M, false>::radix(0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int p0 = t + ord_i<R0>(e) * T;
+        cf z0 = row3_z<N, SLAB>(baseA, baseB, rowA, rowB, ks, sstride, p0);
+        cf z1 = row3_z<N, SLAB>(baseA, baseB, rowA, rowB, ks, sstride, p0 + M);
+        cf z2 = row3_z<N, SLAB>(baseA, baseB, rowA, rowB, ks, sstride, p0 + 2 * M);
+        fft3<+1>(z0, z1, z2);                                   // z_r = sum_j Z[p0 + M j] exp(+2 pi i r j / 3)
+        const cf g = r == 0 ? z0 : (r == 1 ? z1 : z2);
+        reg[e] = r == 0 ? g : cmulc(g, twN[r * p0]);            // * W_N^{-r p0}
+    }
+}
+
+// forward output: twiddle, radix-3 combine across the three groups through LDS, untangle, store rows A, B of T
+template <int M, bool SLAB>
+FB_DEV void row3_store(cf *lds_pair, int r, int t, const cf *reg, bool valid, cf *T_, int rowA, int rowB, int ks, long sstride,
+                       const cf *__restrict__ twN)
+{
+    constexpr int N = 3 * M, T = M / 16, LSTR = Row3Cfg<M>::LSTR, RL = RowTw<M, true>::radix(RowPlan<M>::S - 1);
+    lds_barrier();                                              // the last stage's readers are done
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int k0 = t + ord_i<RL>(e) * T;
+        lds_pair[r * LSTR + lds_pad(k0)] = r == 0 ? reg[e] : cmul(reg[e], twN[r * k0]);     // W_N^{r k0} F_r[k0]
+    }
+    lds_barrier();
+    auto zval = [&](int k) {                                    // Z[k] = sum_r W_3^{r j} CB[r][k0], k = k0 + M j
+        const int j = k / M, k0 = k - j * M;
+        cf c0 = lds_pair[lds_pad(k0)], c1 = lds_pair[LSTR + lds_pad(k0)], c2 = lds_pair[2 * LSTR + lds_pad(k0)];
+        fft3<-1>(c0, c1, c2);
+        return j == 0 ? c0 : (j == 1 ? c1 : c2);
+    };
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = (r * 8 + i) * T + t;                  // all k in [0, N/2)
+            const cf zk = zval(k), zn = k == 0 ? zk : zval(N - k);
+            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, k)) = cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, k)) = cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
+        }
+        if (r == 0 && t == 0) {                                 // Nyquist: its own mirror
+            const cf z = zval(N / 2);
+            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, N / 2)) = cf_make(z.x, 0.f);
+            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, N / 2)) = cf_make(z.y, 0.f);
+        }
+    }
+}
+
+template <int M, int MODE, bool SLAB>
+__global__ void __launch_bounds__(Row3Cfg<M>::THREADS) k_row3(RowArgs a, const cf *__restrict__ twN)
+{
+    using C = Row3Cfg<M>;
+    constexpr int N = C::N, T = C::T, PT = C::PT, GP = C::GP;
+    constexpr int RL = RowTw<M, false>::radix(RowPlan<M>::S - 1);      // physical-space register order
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *smem = reinterpret_cast<cf *>(smem_raw);
+    const int tid = threadIdx.x, gp = tid / PT, q = tid - gp * PT, r = q / T, t = q - r * T;
+    cf *lds_pair = smem + (size_t)gp * 3 * C::LSTR;
+    cf *lds = lds_pair + r * C::LSTR;
+    cf *twl = smem + (size_t)GP * 3 * C::LSTR;
+    RowTwSrc<M, false, true> twb;
+    twb.init(a.tw_bwd, twl, t, tid, C::THREADS);
+    RowTwSrc<M, true, true> twf_own;
+    if (!C::SHARE) twf_own.init(a.tw_fwd, twl + C::TWL_B, t, tid, C::THREADS);
+    __syncthreads();
+
+    const int npairs = a.nx >> 1;
+    const int iters = (npairs + gridDim.x * GP - 1) / (gridDim.x * GP);
+    for (int it = 0; it < iters; ++it) {
+        const int pr = (it * gridDim.x + blockIdx.x) * GP + gp;
+        const bool valid = pr < npairs;
+        const int x0 = valid ? 2 * pr : 0, x1 = x0 + 1;
+        const int tl = launder(t);
+        cf reg[16];
+        if (MODE == ROW_FUSED) {
+            float t0[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) t0[e] = 0.f;
+#pragma unroll 1
+            for (int rr = 0; rr < 2; ++rr) {
+                const int x = x0 + rr;
+                float zx[16], zy[16];
+                row3_load<M, SLAB>(reg, r, launder(t), a.M, a.M + a.m_fstride, x, x, a.ks, a.m_sstride, twN);
+                row_fft<M, false>(lds, launder(t), twb, reg);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { zx[e] = reg[e].x * a.scale; zy[e] = reg[e].y * a.scale; }   // main.cpp:154,168
+                row3_load<M, SLAB>(reg, r, launder(t), a.M + 2 * a.m_fstride, a.M + 3 * a.m_fstride, x, x, a.ks, a.m_sstride, twN);
+                row_fft<M, false>(lds, launder(t), twb, reg);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float u = -(reg[e].x * a.scale);            // main.cpp:200-201
+                    const float v = reg[e].y * a.scale;               // main.cpp:214
+                    const int y = 3 * (tl + ord_i<RL>(e) * T) + r;
+                    const float s = a.src ? a.src[(size_t)x * N + y] : 0.0f;
+                    const float val = -u * zx[e] - v * zy[e] + s;     // main.cpp:225-227
+                    reg[e] = cf_make(t0[e], val);
+                    t0[e] = val;
+                }
+            }
+        } else if (MODE == ROW_FWD) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int y = 3 * (tl + ord_i<RL>(e) * T) + r;
+                reg[e] = cf_make(a.rin[(size_t)x0 * N + y], a.rin[(size_t)x1 * N + y]);
+            }
+        }
+        if (MODE == ROW_FUSED || MODE == ROW_FWD) {
+            if constexpr (C::SHARE) row_fft<M, true>(lds, launder(t), reinterpret_cast<const RowTwSrc<M, true, true> &>(twb), reg);
+            else row_fft<M, true>(lds, launder(t), twf_own, reg);
+            row3_store<M, SLAB>(lds_pair, r, launder(t), reg, valid, a.T, x0, x1, a.ks, a.t_sstride, twN);
+        } else {
+            row3_load<M, SLAB>(reg, r, launder(t), a.M, a.M, x0, x1, a.ks, a.m_sstride, twN);
+            row_fft<M, false>(lds, launder(t), twb, reg);
+            if (valid) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int y = 3 * (tl + ord_i<RL>(e) * T) + r;
+                    a.rout[(size_t)x0 * N + y] = reg[e].x * a.scale;
+                    a.rout[(size_t)x1 * N + y] = reg[e].y * a.scale;
+                }
+            }
+        }
+    }
+}

@@ -11,6 +11,7 @@
 #include "../../include/fftbaro.h"
 #include "fb_kernels.h"
 #include "fb_col_full.h"
+#include "fb_row3.h"
 
 // --------------------------------------------------------------------------------------------
 // errors
@@ -41,10 +42,9 @@ extern "C" const char *fb_last_error(void) { return g_last_error.c_str(); }
 extern "C" int fb_version(void) { return 100; }
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
-extern "C" int fb_size_supported(int nx, int ny)
-{
-    return is_pow2(nx) && is_pow2(ny) && nx >= 64 && nx <= 16384 && ny >= 64 && ny <= 16384;
-}
+// powers of two 64..16384, or 3*2^k in 192..3072 (the reference's default NPTS = 768)
+static bool size_ok(int n) { return (is_pow2(n) && n >= 64 && n <= 16384) || (n % 3 == 0 && is_pow2(n / 3) && n >= 192 && n <= 3072); }
+extern "C" int fb_size_supported(int nx, int ny) { return size_ok(nx) && size_ok(ny); }
 
 // --------------------------------------------------------------------------------------------
 // context
@@ -59,6 +59,7 @@ struct fb_ctx {
     // device tables
     float *d_gx; double *d_kx2; float *d_gy; double *d_ky2; double gws;
     cf *d_tw_n1, *d_tw_n2, *d_tw_big, *d_tw_row_bwd, *d_tw_row_fwd, *d_tw_256;
+    cf *d_tw_row3;              // W_ny^j for ny = 3*M (row pass = radix 3 x three length-M transforms), else NULL
     int col_chunks;             // x pass of a stage is issued in this many column chunks (Infinity-Cache reuse)
     int nct_active;             // local column tiles that contain at least one unmasked ky (the rest is frozen forever)
     bool nyq_frozen;            // the ky = ny/2 column lies outside the dealiasing circle (always on square grids)
@@ -70,6 +71,7 @@ struct fb_ctx {
 
 static void split_nx(int nx, int &N1, int &N2)
 {
+    if (nx % 3 == 0) { N1 = 24; N2 = nx / 24; return; }      // 3*2^k: a 24-row strided sub-pass (radix 3 x 8)
     switch (nx) {
     case 64: N1 = 8; N2 = 8; break;
     case 128: N1 = 16; N2 = 8; break;
@@ -162,7 +164,7 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
     if (world < 1 || rank < 0 || rank >= world || !is_pow2(world) || (nx / world) < 2)
         return fail(FB_EINVAL, "fb_create_slab: world must be a power of two with nx/world >= 2, 0 <= rank < world");
     if (!fb_size_supported(nx, ny))
-        return fail(FB_EUNSUPPORTED, "fb_create: nx, ny must be powers of two in [64, 16384]");
+        return fail(FB_EUNSUPPORTED, "fb_create: nx, ny must be powers of two in [64, 16384] or 3*2^k in [192, 3072]");
     if (!(lx > 0.f) || !(ly > 0.f)) return fail(FB_EINVAL, "fb_create: Lx, Ly must be positive");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -204,10 +206,12 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
         (rc = upload(&c->d_gy, c->h_gy)) || (rc = upload(&c->d_ky2, c->h_ky2)) ||
         (rc = upload(&c->d_tw_n1, make_root_table(c->N1))) || (rc = upload(&c->d_tw_n2, make_root_table(c->N2))) ||
         (rc = upload(&c->d_tw_big, make_root_table(nx))) || (rc = upload(&c->d_tw_256, make_root_table(256))) ||
-        (rc = upload(&c->d_tw_row_bwd, make_row_table(ny, plan_radices_rt(ny, false)))) ||
-        (rc = upload(&c->d_tw_row_fwd, make_row_table(ny, plan_radices_rt(ny, true))))) {
+        (rc = upload(&c->d_tw_row_bwd, make_row_table(ny % 3 ? ny : ny / 3, plan_radices_rt(ny % 3 ? ny : ny / 3, false)))) ||
+        (rc = upload(&c->d_tw_row_fwd, make_row_table(ny % 3 ? ny : ny / 3, plan_radices_rt(ny % 3 ? ny : ny / 3, true))))) {
         delete c; return rc;
     }
+    c->d_tw_row3 = nullptr;
+    if (ny % 3 == 0 && (rc = upload(&c->d_tw_row3, make_root_table(ny)))) { delete c; return rc; }
     hipDeviceProp_t prop;
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
@@ -222,6 +226,7 @@ extern "C" int fb_destroy(fb_ctx *c)
     if (!c) return FB_OK;
     hipFree(c->d_gx); hipFree(c->d_kx2); hipFree(c->d_gy); hipFree(c->d_ky2);
     hipFree(c->d_tw_n1); hipFree(c->d_tw_n2); hipFree(c->d_tw_big); hipFree(c->d_tw_row_bwd); hipFree(c->d_tw_row_fwd); hipFree(c->d_tw_256);
+    if (c->d_tw_row3) hipFree(c->d_tw_row3);
     if (c->d_scratch) hipFree(c->d_scratch);
     delete c;
     return FB_OK;
@@ -417,9 +422,27 @@ template <int N, int MODE> static int launch_row_t(fb_ctx *c, const RowArgs &a)
     return FB_OK;
 }
 
+template <int M, int MODE> static int launch_row3_t(fb_ctx *c, const RowArgs &a)
+{
+    using C = Row3Cfg<M>;
+    const int npairs = a.nx / 2;
+    int grid = (npairs + C::GP - 1) / C::GP;
+    if (grid > c->max_wg) grid = c->max_wg;
+    const bool slab = a.m_sstride != 0 || a.t_sstride != 0;
+    auto kern = slab ? k_row3<M, MODE, true> : k_row3<M, MODE, false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, c->stream, a, (const cf *)c->d_tw_row3);
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
 template <int MODE> static int launch_row(fb_ctx *c, const RowArgs &a)
 {
     switch (c->ny) {
+    case 192: return launch_row3_t<64, MODE>(c, a);
+    case 384: return launch_row3_t<128, MODE>(c, a);
+    case 768: return launch_row3_t<256, MODE>(c, a);
+    case 1536: return launch_row3_t<512, MODE>(c, a);
+    case 3072: return launch_row3_t<1024, MODE>(c, a);
     case 64: return launch_row_t<64, MODE>(c, a);
     case 128: return launch_row_t<128, MODE>(c, a);
     case 256: return launch_row_t<256, MODE>(c, a);
@@ -441,12 +464,14 @@ static int col_grid(const fb_ctx *c, long ntiles)
 }
 
 // natural rows (one block) or, for the 4-field exchange buffer of a slab model, [dst][field][XL][KS]
-static RowMap rowmap_natural() { RowMap r; r.xl_shift = 31; r.xl_mask = 0x7fffffff; r.dstride = 0; return r; }
+static RowMap rowmap_natural() { RowMap r; r.xl_shift = 31; r.xl_mask = 0x7fffffff; r.dstride = 0; r.xl = 0; return r; }
 static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 static RowMap rowmap_w4(const fb_ctx *c)
 {
     if (c->world == 1) return rowmap_natural();
-    RowMap r; r.xl_shift = ilog2(c->XL); r.xl_mask = c->XL - 1; r.dstride = 4L * c->XL * c->P; return r;
+    RowMap r; r.xl_shift = ilog2(c->XL); r.xl_mask = c->XL - 1; r.dstride = 4L * c->XL * c->P;
+    r.xl = is_pow2(c->XL) ? 0 : c->XL;
+    return r;
 }
 static long w4_fstride(const fb_ctx *c) { return c->world == 1 ? (long)c->nx * c->P : (long)c->XL * c->P; }
 
@@ -459,6 +484,7 @@ template <int DIR> static int launch_col_strided(fb_ctx *c, cf *data, int nfield
     const long ntiles = (long)nfields * c->N2 * nct;
     const dim3 g(col_grid(c, ntiles)), b(256);
     switch (c->N1) {
+    case 24: hipLaunchKernelGGL((k_col_strided<24, DIR>), g, b, 0, c->stream, a); break;
     case 8: hipLaunchKernelGGL((k_col_strided<8, DIR>), g, b, 0, c->stream, a); break;
     case 16: hipLaunchKernelGGL((k_col_strided<16, DIR>), g, b, 0, c->stream, a); break;
     case 32: hipLaunchKernelGGL((k_col_strided<32, DIR>), g, b, 0, c->stream, a); break;

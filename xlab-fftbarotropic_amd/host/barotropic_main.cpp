@@ -94,9 +94,9 @@ struct RecordWriter {
 
 int main(int argc, char *args[])
 {
-    // configuration.hpp:10-41 defaults (NPTS 768 is not a power of two: see DESIGN.md, "out of scope")
+    // configuration.hpp:10-41 defaults (NPTS = 768, configuration.hpp:18)
     std::string input = "input", output = "output", init_file = "initial_vorticity.bin", vort_src_filename;
-    int npts = 1024, record_step = 100, total_steps = -1, start_step = 0;
+    int npts = 768, record_step = 100, total_steps = -1, start_step = 0;
     float LX = 600000.0f, LY = 600000.0f, NU = 6.5f, dt = 3.0f;
     RECIPE_TYPE recipe_type = EMPTY;
     static struct option lopts[] = {{"npts", 1, 0, 1}, {"lx", 1, 0, 2}, {"ly", 1, 0, 3}, {"nu", 1, 0, 4}, {"dt", 1, 0, 5},

@@ -24,7 +24,7 @@ int main(int argc, char *args[])
 {
     const float rho = 1.0f, f = 1e-5;                                  // configuration.hpp:10-11
     size_t ref_x = 0, ref_y = 0;
-    int npts = 1024; float LX = 600000.0f, LY = 600000.0f;
+    int npts = 768; float LX = 600000.0f, LY = 600000.0f;
     static struct option lopts[] = {{"npts", 1, 0, 1}, {"lx", 1, 0, 2}, {"ly", 1, 0, 3}, {0, 0, 0, 0}};
     int opt;
     while ((opt = getopt_long(argc, args, "x:y:", lopts, NULL)) != EOF) {

@@ -14,7 +14,7 @@
 
 int main(int argc, char *args[])
 {
-    int npts = 1024, total_steps = -1;
+    int npts = 768, total_steps = -1;
     float LX = 600000.0f, LY = 600000.0f, dt = 3.0f, duration = 3600.0 * 3.0, beg_time = 3600.0 * 2.0;   // :36-37
     static struct option lopts[] = {{"npts", 1, 0, 1}, {"lx", 1, 0, 2}, {"ly", 1, 0, 3}, {"dt", 1, 0, 5}, {"steps", 1, 0, 6},
                                     {"beg-time", 1, 0, 7}, {"duration", 1, 0, 8}, {0, 0, 0, 0}};
