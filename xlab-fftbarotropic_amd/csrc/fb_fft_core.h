@@ -223,6 +223,12 @@ FB_DEV void wave_fft_B2A(const cf *in /*[NLB]*/, float4 *out /*[n/8]*/, cf *lds,
 // radix R when fed from registers):  reg[m*R + q]  <->  position (t + m*T) + q*N/R.
 // ============================================================================================
 FB_DEV int lds_pad(int e) { return e + (e >> 4); }
+// Pacing of the strided x sub-pass: a wave's eight loads (or stores) touch rows ~1 MB apart; issued in one
+// burst they measured 0.118 ms per launch at 4096^2, with 256 idle cycles between them 0.093 ms (128 and 384
+// cycles: 0.106 / 0.094; 512+: slower again) -- most likely DRAM bank/channel conflicts of the large power-of-
+// two-ish stride.  Applied only when the arrays are far larger than the caches (ColArgs::pace).
+FB_DEV void access_gap(int pace) { if (pace) __builtin_amdgcn_s_sleep(4); }
+
 // Opaque copy of a per-thread index: address arithmetic derived from it cannot be hoisted out
 // of the enclosing loop (LICM would otherwise keep dozens of invariant addresses live in VGPRs).
 FB_DEV int launder(int v) { asm volatile("" : "+v"(v)); return v; }

@@ -411,6 +411,7 @@ struct ColArgs {
     long fstride;
     RowMap rm;
     int ct0, nct;      // column tiles [ct0, ct0+nct) are processed (frozen high-ky tiles are skipped per stage)
+    int pace;          // 1: idle 256 cycles between a wave's consecutive strided accesses (large grids)
     int nfields;
     int P;             // pitch (complex)
     int N1, N2;        // nx = N1*N2
@@ -437,8 +438,10 @@ __global__ void __launch_bounds__(256) k_col_strided(ColArgs a)
         cf *base = a.data + (size_t)f * a.fstride + ct * 16;
         float4 in[W::NLA];
 #pragma unroll
-        for (int m = 0; m < W::NLA; ++m)
+        for (int m = 0; m < W::NLA; ++m) {
             in[m] = *reinterpret_cast<const float4 *>(base + a.rm.off((g + 8 * m) * a.N2 + b, a.P) + 2 * cp);
+            access_gap(a.pace);
+        }
         cf out[W::NLB];
         wave_fft_A2B<n, DIR>(in, out, lds, a.tw_n, lane);
         if (W::lb_active(lane)) {
@@ -448,6 +451,7 @@ __global__ void __launch_bounds__(256) k_col_strided(ColArgs a)
                 for (int q = 0; q < 8; ++q) {
                     const int k = h + 4 * s + W::R1 * q;
                     base[a.rm.off(k * a.N2 + b, a.P) + c] = out[s * 8 + q];
+                    access_gap(a.pace);
                 }
         }
     }
@@ -559,7 +563,7 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
 #pragma unroll
             for (int m = 0; m < W::NLA; ++m) {
                 float4 v = *reinterpret_cast<const float4 *>(a.Tin + tbase + (size_t)(g + 8 * m) * a.P + 2 * cp);
-                const cf wb = a.tw_big[(g + 8 * m) * cb];
+                                const cf wb = a.tw_big[(g + 8 * m) * cb];
                 cf p0 = cmul(cf_make(v.x, v.y), wb), p1 = cmul(cf_make(v.z, v.w), wb);
                 in[m] = make_float4(p0.x, p0.y, p1.x, p1.y);
             }
@@ -586,7 +590,7 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
                                             const float4 t2 = reinterpret_cast<const float4 *>(a.Acc)[sb + jp * 64];
                                             acv[0] = cf_make(t2.x, t2.y); acv[1] = cf_make(t2.z, t2.w); }
                     }
-                    cf accv[2], znv[2];
+                        cf accv[2], znv[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int e = 2 * jp + u, s = e >> 3, q = e & 7;
@@ -683,7 +687,7 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
                 const cf wb = a.tw_big[(gf + 8 * m) * cb];
                 cf p0 = cmulc(cf_make(out[m].x, out[m].y), wb), p1 = cmulc(cf_make(out[m].z, out[m].w), wb);
                 *reinterpret_cast<float4 *>(dst + (size_t)(gf + 8 * m) * a.P + 2 * cpf) = make_float4(p0.x, p0.y, p1.x, p1.y);
-            }
+                            }
         }
     }
 }

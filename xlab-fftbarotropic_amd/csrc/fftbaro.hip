@@ -60,6 +60,7 @@ struct fb_ctx {
     float *d_gx; double *d_kx2; float *d_gy; double *d_ky2; double gws;
     cf *d_tw_n1, *d_tw_n2, *d_tw_big, *d_tw_row_bwd, *d_tw_row_fwd, *d_tw_256;
     cf *d_tw_row3;              // W_ny^j for ny = 3*M (row pass = radix 3 x three length-M transforms), else NULL
+    int pace_strided;           // pace the strided sub-pass's accesses (fields much larger than the caches)
     int col_chunks;             // x pass of a stage is issued in this many column chunks (Infinity-Cache reuse)
     int nct_active;             // local column tiles that contain at least one unmasked ky (the rest is frozen forever)
     bool nyq_frozen;            // the ky = ny/2 column lies outside the dealiasing circle (always on square grids)
@@ -155,6 +156,8 @@ template <typename T> static int upload(T **dptr, const std::vector<T> &h)
     return FB_OK;
 }
 
+static int autotune_pitch(fb_ctx *c);
+
 extern "C" int fb_create(fb_ctx **out, int nx, int ny, float lx, float ly) { return fb_create_slab(out, nx, ny, lx, ly, 0, 1); }
 
 extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, int rank, int world)
@@ -174,8 +177,9 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
     c->nx = nx; c->ny = ny; c->hy = ny / 2 + 1;
     c->world = world; c->rank = rank; c->XL = nx / world;
     c->P = (c->hy + 16 * world - 1) / (16 * world) * 16;       // columns per slab, multiple of 16
+    if (const char *e = getenv("FB_PITCH_EXTRA")) c->P += 16 * atoi(e);   // tuning hook (disables the autotuner below)
     c->ky0 = rank * c->P;
-    const int Ptot = c->P * world;
+    const int Ptot = (c->P + 64) * world;          // room for the pitch candidates of autotune_pitch()
     split_nx(nx, c->N1, c->N2);
     c->lx = lx; c->ly = ly; c->stream = nullptr; c->d_scratch = nullptr;
 
@@ -199,6 +203,8 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
         c->nct_active = act < 0 ? 0 : (act > c->P / 16 ? c->P / 16 : act);
         if (getenv("FB_NO_COLUMN_SKIP")) c->nct_active = c->P / 16;
         c->col_chunks = 1;
+        c->pace_strided = 0;      // measured: only pays at the unlucky pitch 16*129; off by default (FB_PACE=1 to try)
+        if (const char *e = getenv("FB_PACE")) c->pace_strided = atoi(e) != 0;
         if (const char *e = getenv("FB_COL_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 16) c->col_chunks = v; }
     }
     int rc;
@@ -217,6 +223,7 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
     HIPCHK(hipGetDevice(&dev));
     HIPCHK(hipGetDeviceProperties(&prop, dev));
     c->max_wg = prop.multiProcessorCount * 8;
+    if ((rc = autotune_pitch(c))) { fb_destroy(c); return rc; }
     *out = c;
     return FB_OK;
 }
@@ -480,6 +487,7 @@ template <int DIR> static int launch_col_strided(fb_ctx *c, cf *data, int nfield
     if (nct < 0) nct = c->P / 16 - ct0;
     if (nct == 0) return FB_OK;
     ColArgs a; a.data = data; a.fstride = fstride; a.rm = rm; a.ct0 = ct0; a.nct = nct; a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
+    a.pace = c->pace_strided;
     a.tw_n = c->d_tw_n1; a.tw_big = c->d_tw_big;
     const long ntiles = (long)nfields * c->N2 * nct;
     const dim3 g(col_grid(c, ntiles)), b(256);
@@ -499,6 +507,7 @@ template <int DIR> static int launch_col_strided(fb_ctx *c, cf *data, int nfield
 template <int DIR> static int launch_col_block(fb_ctx *c, cf *data, int nfields, long fstride)
 {
     ColArgs a; a.data = data; a.fstride = fstride; a.rm = rowmap_natural(); a.ct0 = 0; a.nct = c->P / 16; a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
+    a.pace = 0;
     a.tw_n = c->d_tw_n2; a.tw_big = c->d_tw_big;
     const long ntiles = (long)nfields * c->N1 * (c->P / 16);
     const dim3 g(col_grid(c, ntiles)), b(256);
@@ -532,6 +541,41 @@ static int launch_col_mid(fb_ctx *c, const MidArgs &a)
 }
 
 static size_t priv_elems(const fb_ctx *c) { return (size_t)c->nx * c->P; }
+
+// The strided x sub-pass reads rows N2*P*8 bytes apart; how well that stride spreads over the HBM channels
+// depends on the pitch in a way that is specific to the memory controller's address hash (measured on MI355X,
+// backward strided pass of four fields: 4096^2: P = 2064 0.0955 ms, 2080 0.084 ms; 8192^2: P = 4112 0.393 ms,
+// 4128 0.586 ms).  So on large single-GPU grids the pitch is chosen by timing that pass for a few candidates.
+// Results do not depend on the pitch (pad columns are zero and every pass is linear).
+static int autotune_pitch(fb_ctx *c)
+{
+    if (c->world != 1 || getenv("FB_PITCH_EXTRA") || getenv("FB_NO_PITCH_TUNE")) return FB_OK;
+    if ((size_t)c->nx * c->P * sizeof(cf) < ((size_t)32 << 20)) return FB_OK;      // cache-resident grids: nothing to gain
+    const int P0 = c->P, NC = 4;
+    cf *buf = nullptr;
+    if (hipMalloc((void **)&buf, (size_t)c->nx * (P0 + 16 * (NC - 1)) * sizeof(cf)) != hipSuccess) { hipGetLastError(); return FB_OK; }
+    hipMemsetAsync(buf, 0, (size_t)c->nx * (P0 + 16 * (NC - 1)) * sizeof(cf), c->stream);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f; int bestP = P0;
+    for (int k = 0; k < NC; ++k) {
+        c->P = P0 + 16 * k;
+        float tmin = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0, c->stream);
+            int rc = launch_col_strided<+1>(c, buf, 1, 0);
+            hipEventRecord(e1, c->stream);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (rc == FB_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0 && ms < tmin) tmin = ms;
+        }
+        if (tmin < best * 0.97f) { best = tmin; bestP = c->P; }     // a larger pitch must win by 3 % to be taken
+    }
+    c->P = bestP;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(buf);
+    return FB_OK;
+}
 
 static int ensure_scratch(fb_ctx *c)
 {
