@@ -140,7 +140,7 @@ template <int n> struct WaveTile {
     static constexpr bool TM = R1 >= 4;       // state arrays in the tile-major layout (fb_kernels.h)
     static FB_DEV bool lb_active(int lane) { return R1 >= 4 || (lane >> 4) < R1; }
     // register-allocation target of the fused middle kernel (waves per SIMD)
-    static constexpr int MID_MIN_WAVES = n >= 128 ? 1 : (n >= 64 ? 3 : 4);
+    static constexpr int MID_MIN_WAVES = n >= 128 ? 1 : (n >= 64 ? 2 : 4);
 };
 
 template <int n, int DIR>

@@ -310,6 +310,7 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
     if (DMA && iters > 0) {                                   // prologue: phase 0 of the first pair
         bool v; const int x = pair_of(0, v);
         row_dma_issue<N, SLAB>(stg, t, a.M, a.M + a.m_fstride, x, x, a.ks, a.m_sstride, nyqA, nyqB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     for (int it = 0; it < iters; ++it) {
@@ -328,7 +329,9 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
                 float zx[16], zy[16];
                 // ---- phase (r, 0): dvortdx, dvortdy of row x
                 if (DMA) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // vmcnt counts stores too, in order: phase (0,0)'s rows were waited for BEFORE the previous
+                    // pair's stores went out (below / prologue), so that nobody sits on their acknowledgements
+                    if (r == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     lds_barrier();
                     row_ext_from_stage<N>(reg, launder(t), stg, nyqA, nyqB);
                     lds_barrier();
@@ -373,6 +376,7 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
         if (MODE == ROW_FUSED || MODE == ROW_FWD) {
             if constexpr (SHARE) rowfft<N, true>(lds, launder(t), reinterpret_cast<const RowTwSrc<N, true, true> &>(twb), reg);   // main.cpp:237 (y part)
             else rowfft<N, true>(lds, launder(t), twf_own, reg);
+            if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next pair's first rows have landed
             row_store_pair<N, SLAB>(lds, launder(t), reg, valid, a.T, x0, x1, a.ks, a.t_sstride);
         } else {
             row_load_pair<N, SLAB>(reg, launder(t), a.M, a.M, x0, x1, a.ks, a.m_sstride);
@@ -536,13 +540,26 @@ struct MidArgs {
     const cf *tw_n, *tw_big;
 };
 
+// Memory discipline (gfx9 counts loads AND stores on vmcnt, returned in order): a wave that waits for a
+// load issued after a store also waits for that store's acknowledgement.  So no table is read from
+// global memory inside the tile: W_n, this tile's W_nx^{b cb}, gradx_coe and its square sit in LDS
+// (lgkmcnt), the state arrays are read in half-tile batches (all loads, then the arithmetic, then all
+// stores), and the four derivative fields leave with nothing behind them to wait for.
 template <int n>
 __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(MidArgs a)
 {
     using W = WaveTile<n>;
-    __shared__ __attribute__((aligned(16))) cf smem[4 * W::LDS_CF];
+    __shared__ __attribute__((aligned(16))) cf smem[4 * W::LDS_CF + n + 4 * n];
+    __shared__ double s_kx2[4 * n];
+    __shared__ float s_gx[4 * n];
     const int wv = threadIdx.x >> 6;
     cf *lds = smem + wv * W::LDS_CF;
+    cf *twn = smem + 4 * W::LDS_CF;                  // W_n^k, whole workgroup
+    cf *twb = twn + n + wv * n;                      // W_nx^{b cb} of this wave's tile, b = 0..n-1
+    double *kx2t = s_kx2 + wv * n;                   // (double)gradx_coe^2 at kx = cb + N1 d, d = 0..n-1
+    float *gxt = s_gx + wv * n;
+    for (int i = threadIdx.x; i < n; i += 256) twn[i] = a.tw_n[i];
+    __syncthreads();
     const int ntc = a.nct, ntc_all = a.P >> 4;
     const long ntiles = (long)a.N1 * ntc;
     for (long wt = (long)blockIdx.x * 4 + wv; wt < ntiles; wt += (long)gridDim.x * 4) {
@@ -556,81 +573,116 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
         const int col = ct * 16 + c, ky = a.ky0 + col;
         const float gy = a.coef.gy[ky];
         const double ky2 = a.coef.ky2[ky];
+        float4 in[W::NLA];
+        if (a.stage >= 0) {
+#pragma unroll
+            for (int m = 0; m < W::NLA; ++m)
+                in[m] = *reinterpret_cast<const float4 *>(a.Tin + tbase + (size_t)(g + 8 * m) * a.P + 2 * cp);
+        }
+        __builtin_amdgcn_wave_barrier();                        // the previous tile's table readers are done
+#pragma unroll
+        for (int i = 0; i < (n + 63) / 64; ++i) {
+            const int d = lane + 64 * i;
+            if (n >= 64 || d < n) {
+                twb[d] = a.tw_big[d * cb];
+                gxt[d] = a.coef.gx[cb + a.N1 * d];
+                kx2t[d] = a.coef.kx2[cb + a.N1 * d];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
 
         cf zn[W::NLB];                       // state the derivatives are taken of (LB layout)
         if (a.stage >= 0) {
-            float4 in[W::NLA];
 #pragma unroll
             for (int m = 0; m < W::NLA; ++m) {
-                float4 v = *reinterpret_cast<const float4 *>(a.Tin + tbase + (size_t)(g + 8 * m) * a.P + 2 * cp);
-                                const cf wb = a.tw_big[(g + 8 * m) * cb];
-                cf p0 = cmul(cf_make(v.x, v.y), wb), p1 = cmul(cf_make(v.z, v.w), wb);
+                const cf wb = twb[g + 8 * m];
+                cf p0 = cmul(cf_make(in[m].x, in[m].y), wb), p1 = cmul(cf_make(in[m].z, in[m].w), wb);
                 in[m] = make_float4(p0.x, p0.y, p1.x, p1.y);
             }
             cf th[W::NLB];
-            wave_fft_A2B<n, -1>(in, th, lds, a.tw_n, lane);               // main.cpp:237 (x part)
+            wave_fft_A2B<n, -1>(in, th, lds, twn, lane);               // main.cpp:237 (x part)
             if (lb) {
-                // state arrays in the tile-major layout (see state_tm_index): one float4 = elements e, e+1
-                const size_t sb = W::TM ? ((size_t)tile * (W::NLB / 2)) * 64 + lane : 0;
-#pragma unroll
-                for (int jp = 0; jp < W::NLB / 2; ++jp) {
-                    cf z0v[2], zcv[2], acv[2];
-                    // modes outside the dealiasing circle never change (SURVEY note N1): when all 128 elements
-                    // of this wave instruction are masked, the stage state and the accumulator are not touched
-                    bool frozen = false;
-                    if (W::TM) {
-                        const int d0 = h + 4 * ((2 * jp) >> 3) + W::R1 * ((2 * jp) & 7), d1 = h + 4 * ((2 * jp + 1) >> 3) + W::R1 * ((2 * jp + 1) & 7);
-                        const bool mine = coef_mask(a.coef, cb + a.N1 * d0, ky) == 0.0f && coef_mask(a.coef, cb + a.N1 * d1, ky) == 0.0f;
-                        frozen = __all(mine);
-                        const float4 t0 = reinterpret_cast<const float4 *>(a.Zbase)[sb + jp * 64];
-                        z0v[0] = cf_make(t0.x, t0.y); z0v[1] = cf_make(t0.z, t0.w);
-                        if (frozen) { zcv[0] = z0v[0]; zcv[1] = z0v[1]; acv[0] = acv[1] = cf_make(0.f, 0.f); }
-                        else if (a.stage != 0) { const float4 t1 = reinterpret_cast<const float4 *>(a.Zcur)[sb + jp * 64];
-                                            zcv[0] = cf_make(t1.x, t1.y); zcv[1] = cf_make(t1.z, t1.w);
-                                            const float4 t2 = reinterpret_cast<const float4 *>(a.Acc)[sb + jp * 64];
-                                            acv[0] = cf_make(t2.x, t2.y); acv[1] = cf_make(t2.z, t2.w); }
+                // one RK update of element e; dvortdt_c += lvort_c * NU ; rk = dealiase(dvortdt_c)   main.cpp:148,240-243,296
+                auto update = [&](int e, cf z0, cf zcur, cf ac, cf &acc, cf &znew) {
+                    const int d = h + 4 * (e >> 3) + W::R1 * (e & 7), ikx = cb + a.N1 * d;
+                    const float lap = (float)(-(kx2t[d] + ky2));
+                    const float msk = coef_mask(a.coef, ikx, ky);
+                    const cf zc = a.stage == 0 ? z0 : zcur;
+                    cf k = cf_make((th[e].x + (zc.x * lap) * a.nu) * msk, (th[e].y + (zc.y * lap) * a.nu) * msk);
+                    if (a.stage == 0) {            // main.cpp:296
+                        acc = k; znew = cf_make(z0.x + k.x * (a.dt / 2.0f), z0.y + k.y * (a.dt / 2.0f));
+                    } else if (a.stage == 1) {     // main.cpp:299
+                        acc = cf_make(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y);
+                        znew = cf_make(z0.x + k.x * (a.dt / 2.0f), z0.y + k.y * (a.dt / 2.0f));
+                    } else if (a.stage == 2) {     // main.cpp:302
+                        acc = cf_make(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y);
+                        znew = cf_make(z0.x + k.x * a.dt, z0.y + k.y * a.dt);
+                    } else {                       // main.cpp:309-312
+                        acc = ac;
+                        znew = cf_make(z0.x + (ac.x + k.x) * a.dt / 6.0f, z0.y + (ac.y + k.y) * a.dt / 6.0f);
                     }
-                        cf accv[2], znv[2];
+                };
+                if (W::TM) {
+                    // state arrays in the tile-major layout (see k_state_relayout): one float4 = elements e, e+1
+                    constexpr int JH = W::NLB / 4;              // float4 per lane and array in a half-tile batch
+                    const size_t sb = ((size_t)tile * (W::NLB / 2)) * 64 + lane;
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int e = 2 * jp + u, s = e >> 3, q = e & 7;
-                        const int d = h + 4 * s + W::R1 * q, ikx = cb + a.N1 * d;
-                        const size_t off = tbase + (size_t)d * a.P + c;
-                        const float lap = (float)(-(a.coef.kx2[ikx] + ky2));
-                        const float msk = coef_mask(a.coef, ikx, ky);
-                        const cf z0 = W::TM ? z0v[u] : a.Zbase[off];
-                        const cf zc = a.stage == 0 ? z0 : (W::TM ? zcv[u] : a.Zcur[off]);
-                        // dvortdt_c += lvort_c * NU ; rk = dealiase(dvortdt_c)   main.cpp:148,240-243,296
-                        cf k = cf_make((th[e].x + (zc.x * lap) * a.nu) * msk, (th[e].y + (zc.y * lap) * a.nu) * msk);
-                        cf acc, znew;
-                        if (a.stage == 0) {            // main.cpp:296
-                            acc = k; znew = cf_make(z0.x + k.x * (a.dt / 2.0f), z0.y + k.y * (a.dt / 2.0f));
-                        } else if (a.stage == 1) {     // main.cpp:299
-                            const cf ac = W::TM ? acv[u] : a.Acc[off];
-                            acc = cf_make(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y);
-                            znew = cf_make(z0.x + k.x * (a.dt / 2.0f), z0.y + k.y * (a.dt / 2.0f));
-                        } else if (a.stage == 2) {     // main.cpp:302
-                            const cf ac = W::TM ? acv[u] : a.Acc[off];
-                            acc = cf_make(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y);
-                            znew = cf_make(z0.x + k.x * a.dt, z0.y + k.y * a.dt);
-                        } else {                       // main.cpp:309-312
-                            const cf ac = W::TM ? acv[u] : a.Acc[off];
-                            acc = ac;
-                            znew = cf_make(z0.x + (ac.x + k.x) * a.dt / 6.0f, z0.y + (ac.y + k.y) * a.dt / 6.0f);
+                    for (int hb = 0; hb < 2; ++hb) {
+                        float4 q0[JH], q1[JH], q2[JH];
+                        bool frozen[JH];
+                        // modes outside the dealiasing circle never change (SURVEY note N1): when all 128 elements
+                        // of a wave instruction are masked, the stage state and the accumulator are not touched
+#pragma unroll
+                        for (int j = 0; j < JH; ++j) {
+                            const int jp = hb * JH + j;
+                            const int d0 = h + 4 * ((2 * jp) >> 3) + W::R1 * ((2 * jp) & 7), d1 = h + 4 * ((2 * jp + 1) >> 3) + W::R1 * ((2 * jp + 1) & 7);
+                            const bool mine = coef_mask(a.coef, cb + a.N1 * d0, ky) == 0.0f && coef_mask(a.coef, cb + a.N1 * d1, ky) == 0.0f;
+                            frozen[j] = __all(mine);
                         }
-                        if (!W::TM) {
-                            if (a.stage < 3) { a.Acc[off] = acc; a.Zcur[off] = znew; }
-                            else a.Zout[off] = znew;
+#pragma unroll
+                        for (int j = 0; j < JH; ++j) {
+                            const int jp = hb * JH + j;
+                            q0[j] = reinterpret_cast<const float4 *>(a.Zbase)[sb + jp * 64];
+                            if (!frozen[j] && a.stage != 0) {
+                                q1[j] = reinterpret_cast<const float4 *>(a.Zcur)[sb + jp * 64];
+                                q2[j] = reinterpret_cast<const float4 *>(a.Acc)[sb + jp * 64];
+                            } else q1[j] = q2[j] = make_float4(0.f, 0.f, 0.f, 0.f);   // never looked at: masked, or stage 0
                         }
-                        accv[u] = acc; znv[u] = znew;
-                        zn[e] = znew;
+#pragma unroll
+                        for (int j = 0; j < JH; ++j) {
+                            const int e = 2 * (hb * JH + j);
+                            cf acc0, acc1;
+                            const float4 zq = frozen[j] ? q0[j] : q1[j];
+                            update(e, cf_make(q0[j].x, q0[j].y), cf_make(zq.x, zq.y), cf_make(q2[j].x, q2[j].y), acc0, zn[e]);
+                            update(e + 1, cf_make(q0[j].z, q0[j].w), cf_make(zq.z, zq.w), cf_make(q2[j].z, q2[j].w), acc1, zn[e + 1]);
+                            q2[j] = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
+                        }
+#pragma unroll
+                        for (int j = 0; j < JH; ++j) {
+                            const int jp = hb * JH + j, e = 2 * jp;
+                            if (frozen[j]) continue;
+                            const float4 zo = make_float4(zn[e].x, zn[e].y, zn[e + 1].x, zn[e + 1].y);
+                            if (a.stage < 3) {
+                                reinterpret_cast<float4 *>(a.Acc)[sb + jp * 64] = q2[j];
+                                reinterpret_cast<float4 *>(a.Zcur)[sb + jp * 64] = zo;
+                            } else reinterpret_cast<float4 *>(a.Zout)[sb + jp * 64] = zo;
+                        }
                     }
-                    if (W::TM && !frozen) {
-                        const float4 zo = make_float4(znv[0].x, znv[0].y, znv[1].x, znv[1].y);
-                        if (a.stage < 3) {
-                            reinterpret_cast<float4 *>(a.Acc)[sb + jp * 64] = make_float4(accv[0].x, accv[0].y, accv[1].x, accv[1].y);
-                            reinterpret_cast<float4 *>(a.Zcur)[sb + jp * 64] = zo;
-                        } else reinterpret_cast<float4 *>(a.Zout)[sb + jp * 64] = zo;
+                } else {
+                    cf z0[W::NLB], zc[W::NLB], ac[W::NLB];
+#pragma unroll
+                    for (int e = 0; e < W::NLB; ++e) {
+                        const size_t off = tbase + (size_t)(h + 4 * (e >> 3) + W::R1 * (e & 7)) * a.P + c;
+                        z0[e] = a.Zbase[off];
+                        if (a.stage != 0) { zc[e] = a.Zcur[off]; ac[e] = a.Acc[off]; } else { zc[e] = z0[e]; ac[e] = cf_make(0.f, 0.f); }
+                    }
+#pragma unroll
+                    for (int e = 0; e < W::NLB; ++e) update(e, z0[e], zc[e], ac[e], ac[e], zn[e]);
+#pragma unroll
+                    for (int e = 0; e < W::NLB; ++e) {
+                        const size_t off = tbase + (size_t)(h + 4 * (e >> 3) + W::R1 * (e & 7)) * a.P + c;
+                        if (a.stage < 3) { a.Acc[off] = ac[e]; a.Zcur[off] = zn[e]; }
+                        else a.Zout[off] = zn[e];
                     }
                 }
             }
@@ -649,6 +701,10 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
                     for (int q = 0; q < 8; ++q)
                         zn[s * 8 + q] = a.Zbase[tbase + (size_t)(h + 4 * s + W::R1 * q) * a.P + c];
             }
+            // land the loads here: otherwise the wait sits in front of the derivative loop for every
+            // path, and the stage path would wait for its state stores there
+#pragma unroll
+            for (int e = 0; e < W::NLB; ++e) asm volatile("" :: "v"(zn[e].x), "v"(zn[e].y));
         }
 
         // derivatives of zn through the backward block sub-pass: f0 gradx(vort), f1 grady(vort),
@@ -665,7 +721,7 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {                 // main.cpp:179, fftwfop.cpp:112-117
                             const int e = s * 8 + q, d = hf + 4 * s + W::R1 * q, ikx = cb + a.N1 * d;
-                            const float li = (ikx == 0 && ky == 0) ? 1.0f : (float)(-(a.coef.kx2[ikx] + ky2));
+                            const float li = (ikx == 0 && ky == 0) ? 1.0f : (float)(-(kx2t[d] + ky2));
                             zn[e] = (ky < a.coef.hy) ? cf_make(zn[e].x / li, zn[e].y / li) : cf_make(0.f, 0.f);
                         }
                 }
@@ -674,20 +730,20 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
                 for (int s = 0; s < W::NP; ++s)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const int e = s * 8 + q, d = hf + 4 * s + W::R1 * q, ikx = cb + a.N1 * d;
-                        const float kk = use_gx ? a.coef.gx[ikx] : gy;
+                        const int e = s * 8 + q, d = hf + 4 * s + W::R1 * q;
+                        const float kk = use_gx ? gxt[d] : gy;
                         fld[e] = cf_make(-zn[e].y * kk, zn[e].x * kk);                // fftwfop.cpp:87-103
                     }
             }
             float4 out[W::NLA];
-            wave_fft_B2A<n, +1>(fld, out, lds, a.tw_n, lf);
+            wave_fft_B2A<n, +1>(fld, out, lds, twn, lf);
             cf *dst = a.W4 + (size_t)f * a.fstride + a.rm.off(cb * n, a.P) + ct * 16;      // a block of n rows never straddles a rank
 #pragma unroll
             for (int m = 0; m < W::NLA; ++m) {
-                const cf wb = a.tw_big[(gf + 8 * m) * cb];
+                const cf wb = twb[gf + 8 * m];
                 cf p0 = cmulc(cf_make(out[m].x, out[m].y), wb), p1 = cmulc(cf_make(out[m].z, out[m].w), wb);
                 *reinterpret_cast<float4 *>(dst + (size_t)(gf + 8 * m) * a.P + 2 * cpf) = make_float4(p0.x, p0.y, p1.x, p1.y);
-                            }
+            }
         }
     }
 }
