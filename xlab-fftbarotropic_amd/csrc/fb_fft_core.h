@@ -5,19 +5,65 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-typedef float2 cf;
+// A complex number is a native 2-vector: it lives in an aligned VGPR pair and add/sub map to one
+// packed instruction (v_pk_add_f32).  Everything that needs a lane swizzle (complex multiply,
+// multiplication by +-i folded into an add) is spelled with VOP3P op_sel/neg modifiers below:
+// the compiler's own selection spends 4-5 instructions and register moves per complex multiply.
+typedef float cf __attribute__((ext_vector_type(2)));
 
 #define FB_DEV __device__ __forceinline__
 
-FB_DEV cf cf_make(float x, float y) { cf r; r.x = x; r.y = y; return r; }
-FB_DEV cf cadd(cf a, cf b) { return cf_make(a.x + b.x, a.y + b.y); }
-FB_DEV cf csub(cf a, cf b) { return cf_make(a.x - b.x, a.y - b.y); }
+FB_DEV cf cf_make(float x, float y) { cf r = {x, y}; return r; }
+FB_DEV cf cadd(cf a, cf b) { return a + b; }
+FB_DEV cf csub(cf a, cf b) { return a - b; }
+#if defined(__HIP_DEVICE_COMPILE__)
+// a*b = (a.x b.x - a.y b.y, a.x b.y + a.y b.x):  t = (a.y b.y, a.y b.x);  r = (a.x b.x - t.x, a.x b.y + t.y)
+FB_DEV cf cmul(cf a, cf b)
+{
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// a*conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
+FB_DEV cf cmulc(cf a, cf b)
+{
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// same with the second factor in an SGPR pair (compile-time constants)
+FB_DEV cf cmul_k(cf a, cf k)
+{
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(k));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "s"(k), "v"(t));
+    return r;
+}
+// a + i b = (a.x - b.y, a.y + b.x) ;  a - i b = (a.x + b.y, a.y - b.x)
+FB_DEV cf cadd_ib(cf a, cf b)
+{
+    cf r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+FB_DEV cf csub_ib(cf a, cf b)
+{
+    cf r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+#else
 FB_DEV cf cmul(cf a, cf b) { return cf_make(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-FB_DEV cf cmulc(cf a, cf b) { return cf_make(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
+FB_DEV cf cmulc(cf a, cf b) { return cf_make(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+FB_DEV cf cmul_k(cf a, cf k) { return cmul(a, k); }
+FB_DEV cf cadd_ib(cf a, cf b) { return cf_make(a.x - b.y, a.y + b.x); }
+FB_DEV cf csub_ib(cf a, cf b) { return cf_make(a.x + b.y, a.y - b.x); }
+#endif
 // multiply by the direction's table twiddle: forward uses w, backward conj(w)
 template <int DIR> FB_DEV cf cmul_dir(cf a, cf w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
 // multiply by -i (forward) or +i (backward)
 template <int DIR> FB_DEV cf mul_mi(cf a) { return DIR < 0 ? cf_make(a.y, -a.x) : cf_make(-a.y, a.x); }
+// a + (-i b) forward, a + (i b) backward -- and the difference
+template <int DIR> FB_DEV cf cadd_rot(cf a, cf b) { return DIR < 0 ? csub_ib(a, b) : cadd_ib(a, b); }
+template <int DIR> FB_DEV cf csub_rot(cf a, cf b) { return DIR < 0 ? cadd_ib(a, b) : csub_ib(a, b); }
 
 #define FB_SQRT1_2 0.70710678118654752440f
 #define FB_C16_1 0.92387953251128675613f   /* cos(pi/8) */
@@ -29,7 +75,7 @@ template <int M, int DIR> FB_DEV cf mul_w16(cf a)
     constexpr int m = M & 15;
     if constexpr (m == 0) return a;
     else if constexpr (m == 4) return mul_mi<DIR>(a);
-    else if constexpr (m == 8) return cf_make(-a.x, -a.y);
+    else if constexpr (m == 8) return -a;
     else if constexpr (m == 12) return mul_mi<-DIR>(a);
     else {
         // W^m = (c, -s) forward with c = cos(2 pi m/16), s = sin(2 pi m/16)
@@ -40,7 +86,7 @@ template <int M, int DIR> FB_DEV cf mul_w16(cf a)
                             (m == 3 || m == 5) ? FB_C16_1 : (m == 9 || m == 15) ? -FB_S16_1 :
                             (m == 10 || m == 14) ? -FB_SQRT1_2 : /* 11, 13 */ -FB_C16_1;
         constexpr float si = DIR < 0 ? -s : s;       // imaginary part of the twiddle
-        return cf_make(a.x * c - a.y * si, a.x * si + a.y * c);
+        return cmul_k(a, cf_make(c, si));
     }
 }
 
@@ -49,8 +95,8 @@ template <int DIR> FB_DEV void fft2(cf &a, cf &b) { cf t = a; a = cadd(t, b); b 
 
 template <int DIR> FB_DEV void fft4(cf &a0, cf &a1, cf &a2, cf &a3)
 {
-    cf s0 = cadd(a0, a2), s1 = csub(a0, a2), s2 = cadd(a1, a3), s3 = mul_mi<DIR>(csub(a1, a3));
-    a0 = cadd(s0, s2); a1 = cadd(s1, s3); a2 = csub(s0, s2); a3 = csub(s1, s3);
+    cf s0 = cadd(a0, a2), s1 = csub(a0, a2), s2 = cadd(a1, a3), d3 = csub(a1, a3);
+    a0 = cadd(s0, s2); a1 = cadd_rot<DIR>(s1, d3); a2 = csub(s0, s2); a3 = csub_rot<DIR>(s1, d3);
 }
 
 template <int R, int DIR> struct Bfly;
@@ -75,11 +121,11 @@ template <int DIR> struct Bfly<8, DIR> {
         __builtin_amdgcn_sched_barrier(0);
         fft4<DIR>(v[1], v[3], v[5], v[7]);            // odd   -> O[k] in v[1],v[3],v[5],v[7]
         __builtin_amdgcn_sched_barrier(0);
-        cf o1 = mul_w16<2, DIR>(v[3]), o2 = mul_w16<4, DIR>(v[5]), o3 = mul_w16<6, DIR>(v[7]);
+        cf o1 = mul_w16<2, DIR>(v[3]), o2 = v[5], o3 = mul_w16<6, DIR>(v[7]);
         cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
         v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
         v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
-        v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+        v[2] = cadd_rot<DIR>(e2, o2); v[6] = csub_rot<DIR>(e2, o2);          // W_8^2 = -+i
         v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
         __builtin_amdgcn_sched_barrier(0);
     }
