@@ -65,6 +65,27 @@ template <int DIR> FB_DEV cf mul_mi(cf a) { return DIR < 0 ? cf_make(a.y, -a.x) 
 template <int DIR> FB_DEV cf cadd_rot(cf a, cf b) { return DIR < 0 ? csub_ib(a, b) : cadd_ib(a, b); }
 template <int DIR> FB_DEV cf csub_rot(cf a, cf b) { return DIR < 0 ? cadd_ib(a, b) : csub_ib(a, b); }
 
+// ---- streaming ("nontemporal") global accesses --------------------------------------------------
+// FB_NT is a bit mask that selects which streams carry the nt hint (tuning switch):
+//   1 strided sub-pass loads   2 strided sub-pass stores   4 row-pass LDS-DMA loads   8 row-pass stores
+//   16 middle kernel tendency loads   32 middle kernel derivative stores   64 middle kernel state arrays
+#ifndef FB_NT
+#define FB_NT 0
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <bool NT> FB_DEV float4 ld4(const void *p)
+{
+    if (NT) { const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    return *reinterpret_cast<const float4 *>(p);
+}
+template <bool NT> FB_DEV void st4(void *p, float4 v)
+{
+    if (NT) { const f4v t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p)); }
+    else *reinterpret_cast<float4 *>(p) = v;
+}
+template <bool NT> FB_DEV cf ld2(const cf *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> FB_DEV void st2(cf *p, cf v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
 #define FB_SQRT1_2 0.70710678118654752440f
 #define FB_C16_1 0.92387953251128675613f   /* cos(pi/8) */
 #define FB_S16_1 0.38268343236508977173f   /* sin(pi/8) */
@@ -186,7 +207,7 @@ template <int n> struct WaveTile {
     static constexpr bool TM = R1 >= 4;       // state arrays in the tile-major layout (fb_kernels.h)
     static FB_DEV bool lb_active(int lane) { return R1 >= 4 || (lane >> 4) < R1; }
     // register-allocation target of the fused middle kernel (waves per SIMD)
-    static constexpr int MID_MIN_WAVES = n >= 128 ? 1 : (n >= 64 ? 2 : 4);
+    static constexpr int MID_MIN_WAVES = n >= 128 ? 1 : (n >= 64 ? 2 : (n >= 32 ? 4 : 2));   // n < 32: row-layout state path, tiny grids
 };
 
 template <int n, int DIR>
@@ -281,7 +302,11 @@ FB_DEV int launder(int v) { asm volatile("" : "+v"(v)); return v; }
 
 // Workgroup barrier that orders LDS traffic only: waits lgkmcnt(0), not vmcnt, so LDS-DMA
 // prefetches and global stores stay in flight across it (cdna_hip_programming.md, section 5).
+#ifdef FB_NO_LDS_BARRIER   /* timing experiment only (results are wrong): what the workgroup barriers cost */
+FB_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 FB_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // Row plans: radices of the BACKWARD (c2r) row transform; the forward transform walks them
 // reversed, so that the backward pass's final register distribution feeds the forward pass.

@@ -223,8 +223,8 @@ FB_DEV void row_store_pair(cf *lds, int t, const cf *reg, bool valid, cf *T_, in
             const int k = t + i * T;
             const cf zk = reg[e];
             const cf zn = (i == 0 && t == 0) ? zk : lds[lds_pad(N - k - HOFF)];
-            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, k)) = cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, k)) = cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
+            st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, k)), cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)));
+            st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, k)), cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)));
         } else if (i == 8 && t == 0) {                       // Nyquist: its own mirror
             *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, N / 2)) = cf_make(reg[e].x, 0.f);
             *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, N / 2)) = cf_make(reg[e].y, 0.f);
@@ -245,9 +245,9 @@ FB_DEV void row_dma_issue(cf *stg, int t, const cf *baseA, const cf *baseB, int 
         const int ch = w + c * NW, k = ch * 128 + lane * 2;
         cf *dstA = stg + ch * 128, *dstB = stg + N / 2 + ch * 128;   // wave-uniform; the DMA adds lane*16 B
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(baseA, ks, sstride, rowA, k),
-                                         (void __attribute__((address_space(3))) *)dstA, 16, 0, 0);
+                                         (void __attribute__((address_space(3))) *)dstA, 16, 0, (FB_NT & 4) ? 2 : 0);
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(baseB, ks, sstride, rowB, k),
-                                         (void __attribute__((address_space(3))) *)dstB, 16, 0, 0);
+                                         (void __attribute__((address_space(3))) *)dstB, 16, 0, (FB_NT & 4) ? 2 : 0);
     }
     if (t == 0) { nyqA = *row_ptr<SLAB>(baseA, ks, sstride, rowA, N / 2); nyqB = *row_ptr<SLAB>(baseB, ks, sstride, rowB, N / 2); }
 }
@@ -305,7 +305,11 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
     if (!SHARE) twf_own.init(a.tw_fwd, twl + C::TWL_B, t, threadIdx.x, C::THREADS);
     __syncthreads();
 
+#ifdef FB_ROW_SAMEROW   /* timing experiment only: every workgroup works on rows 0,1 (no HBM traffic); results are wrong */
+    auto pair_of = [&](int it, bool &valid) { const int pr = (it * gridDim.x + blockIdx.x) * G + grp; valid = pr < npairs; return 0; };
+#else
     auto pair_of = [&](int it, bool &valid) { const int pr = (it * gridDim.x + blockIdx.x) * G + grp; valid = pr < npairs; return valid ? 2 * pr : 0; };
+#endif
     cf nyqA = cf_make(0.f, 0.f), nyqB = nyqA;
     if (DMA && iters > 0) {                                   // prologue: phase 0 of the first pair
         bool v; const int x = pair_of(0, v);
@@ -443,7 +447,7 @@ __global__ void __launch_bounds__(256) k_col_strided(ColArgs a)
         float4 in[W::NLA];
 #pragma unroll
         for (int m = 0; m < W::NLA; ++m) {
-            in[m] = *reinterpret_cast<const float4 *>(base + a.rm.off((g + 8 * m) * a.N2 + b, a.P) + 2 * cp);
+            in[m] = ld4<(FB_NT & 1) != 0>(base + a.rm.off((g + 8 * m) * a.N2 + b, a.P) + 2 * cp);
             access_gap(a.pace);
         }
         cf out[W::NLB];
@@ -454,7 +458,7 @@ __global__ void __launch_bounds__(256) k_col_strided(ColArgs a)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int k = h + 4 * s + W::R1 * q;
-                    base[a.rm.off(k * a.N2 + b, a.P) + c] = out[s * 8 + q];
+                    st2<(FB_NT & 2) != 0>(&base[a.rm.off(k * a.N2 + b, a.P) + c], out[s * 8 + q]);
                     access_gap(a.pace);
                 }
         }
@@ -577,7 +581,7 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
         if (a.stage >= 0) {
 #pragma unroll
             for (int m = 0; m < W::NLA; ++m)
-                in[m] = *reinterpret_cast<const float4 *>(a.Tin + tbase + (size_t)(g + 8 * m) * a.P + 2 * cp);
+                in[m] = ld4<(FB_NT & 16) != 0>(a.Tin + tbase + (size_t)(g + 8 * m) * a.P + 2 * cp);
         }
         __builtin_amdgcn_wave_barrier();                        // the previous tile's table readers are done
 #pragma unroll
@@ -642,10 +646,10 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
 #pragma unroll
                         for (int j = 0; j < JH; ++j) {
                             const int jp = hb * JH + j;
-                            q0[j] = reinterpret_cast<const float4 *>(a.Zbase)[sb + jp * 64];
+                            q0[j] = ld4<(FB_NT & 64) != 0>(reinterpret_cast<const float4 *>(a.Zbase) + sb + jp * 64);
                             if (!frozen[j] && a.stage != 0) {
-                                q1[j] = reinterpret_cast<const float4 *>(a.Zcur)[sb + jp * 64];
-                                q2[j] = reinterpret_cast<const float4 *>(a.Acc)[sb + jp * 64];
+                                q1[j] = ld4<(FB_NT & 64) != 0>(reinterpret_cast<const float4 *>(a.Zcur) + sb + jp * 64);
+                                q2[j] = ld4<(FB_NT & 64) != 0>(reinterpret_cast<const float4 *>(a.Acc) + sb + jp * 64);
                             } else q1[j] = q2[j] = make_float4(0.f, 0.f, 0.f, 0.f);   // never looked at: masked, or stage 0
                         }
 #pragma unroll
@@ -663,9 +667,9 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
                             if (frozen[j]) continue;
                             const float4 zo = make_float4(zn[e].x, zn[e].y, zn[e + 1].x, zn[e + 1].y);
                             if (a.stage < 3) {
-                                reinterpret_cast<float4 *>(a.Acc)[sb + jp * 64] = q2[j];
-                                reinterpret_cast<float4 *>(a.Zcur)[sb + jp * 64] = zo;
-                            } else reinterpret_cast<float4 *>(a.Zout)[sb + jp * 64] = zo;
+                                st4<(FB_NT & 64) != 0>(reinterpret_cast<float4 *>(a.Acc) + sb + jp * 64, q2[j]);
+                                st4<(FB_NT & 64) != 0>(reinterpret_cast<float4 *>(a.Zcur) + sb + jp * 64, zo);
+                            } else st4<(FB_NT & 64) != 0>(reinterpret_cast<float4 *>(a.Zout) + sb + jp * 64, zo);
                         }
                     }
                 } else {
@@ -742,7 +746,7 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
             for (int m = 0; m < W::NLA; ++m) {
                 const cf wb = twb[gf + 8 * m];
                 cf p0 = cmulc(cf_make(out[m].x, out[m].y), wb), p1 = cmulc(cf_make(out[m].z, out[m].w), wb);
-                *reinterpret_cast<float4 *>(dst + (size_t)(gf + 8 * m) * a.P + 2 * cpf) = make_float4(p0.x, p0.y, p1.x, p1.y);
+                st4<(FB_NT & 32) != 0>(dst + (size_t)(gf + 8 * m) * a.P + 2 * cpf, make_float4(p0.x, p0.y, p1.x, p1.y));
             }
         }
     }

@@ -61,7 +61,10 @@ struct fb_ctx {
     cf *d_tw_n1, *d_tw_n2, *d_tw_big, *d_tw_row_bwd, *d_tw_row_fwd, *d_tw_256;
     cf *d_tw_row3;              // W_ny^j for ny = 3*M (row pass = radix 3 x three length-M transforms), else NULL
     int pace_strided;           // pace the strided sub-pass's accesses (fields much larger than the caches)
-    int col_chunks;             // x pass of a stage is issued in this many column chunks (Infinity-Cache reuse)
+    int col_chunks;             // x pass of a stage is issued in this many column chunks ...
+    int col_streams;            // ... round-robin over this many streams, so that one chunk's kernel tails are filled by the next chunk
+    hipStream_t aux[3];         // the extra streams (created on demand) and the fork/join events
+    hipEvent_t ev_fork, ev_join[3];
     int nct_active;             // local column tiles that contain at least one unmasked ky (the rest is frozen forever)
     bool nyq_frozen;            // the ky = ny/2 column lies outside the dealiasing circle (always on square grids)
     cf *d_scratch;              // nx*P complex, lazily allocated (standalone r2c / c2r)
@@ -206,6 +209,9 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
         c->pace_strided = 0;      // measured: only pays at the unlucky pitch 16*129; off by default (FB_PACE=1 to try)
         if (const char *e = getenv("FB_PACE")) c->pace_strided = atoi(e) != 0;
         if (const char *e = getenv("FB_COL_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 16) c->col_chunks = v; }
+        c->col_streams = 1;
+        if (const char *e = getenv("FB_COL_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->col_streams = v; }
+        if (c->col_streams > c->col_chunks) c->col_streams = c->col_chunks;
     }
     int rc;
     if ((rc = upload(&c->d_gx, c->h_gx)) || (rc = upload(&c->d_kx2, c->h_kx2)) ||
@@ -235,6 +241,8 @@ extern "C" int fb_destroy(fb_ctx *c)
     hipFree(c->d_tw_n1); hipFree(c->d_tw_n2); hipFree(c->d_tw_big); hipFree(c->d_tw_row_bwd); hipFree(c->d_tw_row_fwd); hipFree(c->d_tw_256);
     if (c->d_tw_row3) hipFree(c->d_tw_row3);
     if (c->d_scratch) hipFree(c->d_scratch);
+    for (int i = 0; i < 3; ++i) { if (c->aux[i]) hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
     delete c;
     return FB_OK;
 }
@@ -420,11 +428,13 @@ template <int N, int MODE> static int launch_row_t(fb_ctx *c, const RowArgs &a)
     const bool slab = a.m_sstride != 0 || a.t_sstride != 0;
     auto kern = slab ? k_row<N, MODE, true> : k_row<N, MODE, false>;
     static bool attr_set[2] = {false, false};
+    static size_t lds_extra = 0;              // experiment hook: FB_ROW_LDS_EXTRA=<bytes> lowers the workgroups per CU
     if (!attr_set[slab]) {
-        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        if (const char *e = getenv("FB_ROW_LDS_EXTRA")) lds_extra = (size_t)atol(e);
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDS_BYTES + lds_extra)));
         attr_set[slab] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, c->stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES + lds_extra, c->stream, a);
     HIPCHK(hipGetLastError());
     return FB_OK;
 }
@@ -937,9 +947,24 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
             // ... then the x pass in column chunks, each chained forward -> update -> backward so that a
             // chunk's derivative fields are still in the Infinity Cache when the backward sub-pass reads them
             const int nchunk = c->col_chunks;
+            // chunks are independent of each other: spread over several streams their kernels overlap, and
+            // the drain of one kernel is filled by the next (not while profiling: the events would interleave)
+            const int nstr = (prof || m->use_graph) ? 1 : c->col_streams;
+            hipStream_t main_stream = c->stream;
+            if (nstr > 1) {
+                if (!c->ev_fork) HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                for (int i = 0; i < nstr - 1; ++i) {
+                    if (!c->aux[i]) HIPCHK(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+                    if (!c->ev_join[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+                }
+                HIPCHK(hipEventRecord(c->ev_fork, main_stream));
+                for (int i = 0; i < nstr - 1; ++i) HIPCHK(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
+            }
+            struct StreamGuard { fb_ctx *c; hipStream_t s; ~StreamGuard() { c->stream = s; } } guard{c, main_stream};
             for (int h = 0; h < nchunk; ++h) {
                 const int ct0 = (int)((long)c->nct_active * h / nchunk), ct1 = (int)((long)c->nct_active * (h + 1) / nchunk);
                 if (ct1 == ct0) continue;
+                c->stream = (nstr > 1 && h % nstr) ? c->aux[h % nstr - 1] : main_stream;
                 PROF_BEGIN(2);
                 if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0, rowmap_natural(), ct0, ct1 - ct0))) return rc;
                 PROF_END(2);
@@ -950,6 +975,11 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
                 PROF_BEGIN(0);
                 if ((rc = launch_col_strided<+1>(c, m->w4_send, 4, (long)priv_elems(c), rowmap_natural(), ct0, ct1 - ct0))) return rc;
                 PROF_END(0);
+            }
+            c->stream = main_stream;
+            for (int i = 0; i < nstr - 1; ++i) {
+                HIPCHK(hipEventRecord(c->ev_join[i], c->aux[i]));
+                HIPCHK(hipStreamWaitEvent(main_stream, c->ev_join[i], 0));
             }
         }
     }
