@@ -324,6 +324,45 @@ def test_experimental_single_pass_x_transform(O, R):
     assert R.rel_l2(outs["1"][1].view(np.float32), outs["0"][1].view(np.float32)) < 2e-6
 
 
+def test_row8_matches_stockham_row_kernel(O, R):
+    """fb_row8.h (default at ny = 4096) against the Stockham row kernel (FB_NO_ROW8=1): same maths, different
+    factorisation and physical-space ordering -- with a vorticity source, whose gather follows that ordering.
+    Child processes: the switch is read when the context is created."""
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, numpy as np; sys.path[:0]=[%r, %r]\n"
+        "import xlab_fftbarotropic_amd as X\n"
+        "nx, ny = 512, 4096\n"
+        "rng = np.random.default_rng(5); v0 = rng.standard_normal((nx, ny)).astype(np.float32) * 1e-4\n"
+        "src = rng.standard_normal((nx, ny)).astype(np.float32) * 1e-9\n"
+        "m = X.Model(nx, ny, dt=0.75); m.set_vort(v0); m.set_source(src); m.step(3)\n"
+        "np.save(sys.argv[1], m.vort().cpu().numpy())\n"
+    ) % (os.path.dirname(HERE), HERE)
+    with tempfile.TemporaryDirectory() as d:
+        outs = {}
+        for flag in ("", "1"):
+            env = dict(os.environ)
+            env.pop("FB_NO_ROW8", None)
+            if flag:
+                env["FB_NO_ROW8"] = flag
+            a = os.path.join(d, "v%s.npy" % flag)
+            subprocess.check_call([sys.executable, "-c", code, a], env=env)
+            outs[flag] = np.load(a)
+    assert np.isfinite(outs[""]).all()
+    assert R.rel_l2(outs[""], outs["1"]) < 2e-6
+    # and against the oracle (CPU restatement of main.cpp:146-317)
+    rng = np.random.default_rng(5)
+    v0 = rng.standard_normal((512, 4096)).astype(np.float32) * 1e-4
+    src = rng.standard_normal((512, 4096)).astype(np.float32) * 1e-9
+    mo = O.Model(512, 4096, dt=0.75)
+    mo.set_vort(v0)
+    mo.set_source(src)
+    mo.step(3)
+    assert R.rel_l2(outs[""], mo.vort()) < 1e-5
+
+
 def test_graph_replay_matches_eager(X, torch):
     """fb_model_use_graph: the captured RK4 step replayed as a hipGraph gives bit-identical fields,
     including across a source change (which invalidates the captured kernel arguments)."""

@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "fftbaro.hip")
 SRC_HOST = [os.path.join(HERE, "csrc", "fb_fields.cpp")]
-DEPS = [SRC] + SRC_HOST + [ os.path.join(HERE, "csrc", "fb_kernels.h"), os.path.join(HERE, "csrc", "fb_fft_core.h"), os.path.join(HERE, "csrc", "fb_col_full.h"), os.path.join(HERE, "csrc", "fb_row3.h"),
+DEPS = [SRC] + SRC_HOST + [ os.path.join(HERE, "csrc", "fb_kernels.h"), os.path.join(HERE, "csrc", "fb_fft_core.h"), os.path.join(HERE, "csrc", "fb_col_full.h"), os.path.join(HERE, "csrc", "fb_row3.h"), os.path.join(HERE, "csrc", "fb_row8.h"),
         os.path.join(os.path.dirname(HERE), "include", "fftbaro.h")]
 LIB = os.path.join(HERE, "lib", "libfftbaro.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -12,6 +12,7 @@
 #include "fb_kernels.h"
 #include "fb_col_full.h"
 #include "fb_row3.h"
+#include "fb_row8.h"
 
 // --------------------------------------------------------------------------------------------
 // errors
@@ -59,7 +60,8 @@ struct fb_ctx {
     // device tables
     float *d_gx; double *d_kx2; float *d_gy; double *d_ky2; double gws;
     cf *d_tw_n1, *d_tw_n2, *d_tw_big, *d_tw_row_bwd, *d_tw_row_fwd, *d_tw_256;
-    cf *d_tw_row3;              // W_ny^j for ny = 3*M (row pass = radix 3 x three length-M transforms), else NULL
+    cf *d_tw_row3;              // W_ny^j for ny = 3*M (row pass = radix 3 x three length-M transforms) and ny = 4096 (k_row8), else NULL
+    bool use_row8;              // fused row pass of ny = 4096 through k_row8 (FB_NO_ROW8=1: the Stockham kernel)
     int pace_strided;           // pace the strided sub-pass's accesses (fields much larger than the caches)
     int col_chunks;             // x pass of a stage is issued in this many column chunks ...
     int col_streams;            // ... round-robin over this many streams, so that one chunk's kernel tails are filled by the next chunk
@@ -223,7 +225,8 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
         delete c; return rc;
     }
     c->d_tw_row3 = nullptr;
-    if (ny % 3 == 0 && (rc = upload(&c->d_tw_row3, make_root_table(ny)))) { delete c; return rc; }
+    if ((ny % 3 == 0 || ny == 4096) && (rc = upload(&c->d_tw_row3, make_root_table(ny)))) { delete c; return rc; }   // 4096: k_row8's W_ny^j
+    c->use_row8 = ny == 4096 && !getenv("FB_NO_ROW8");
     hipDeviceProp_t prop;
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
@@ -452,8 +455,26 @@ template <int M, int MODE> static int launch_row3_t(fb_ctx *c, const RowArgs &a)
     return FB_OK;
 }
 
+static int launch_row8(fb_ctx *c, const RowArgs &a)
+{
+    const int npairs = a.nx / 2;
+    int grid = npairs, cap = c->max_wg / 4;   // two resident workgroups per CU, each loops over row pairs
+    if (const char *e = getenv("FB_ROW_GRID")) { int v = atoi(e); if (v >= 64) cap = v; }
+    if (grid > cap) grid = cap;
+    auto kern = k_row8<false>;                // slab-blocked exchange buffers keep the Stockham kernel (launch_row)
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Row8::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Row8::LDS_BYTES, c->stream, a, (const cf *)c->d_tw_row3);
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
 template <int MODE> static int launch_row(fb_ctx *c, const RowArgs &a)
 {
+    if (MODE == ROW_FUSED && c->use_row8 && a.nx >= 2 && a.m_sstride == 0 && a.t_sstride == 0) return launch_row8(c, a);
     switch (c->ny) {
     case 192: return launch_row3_t<64, MODE>(c, a);
     case 384: return launch_row3_t<128, MODE>(c, a);
