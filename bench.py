@@ -27,12 +27,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 ALG_N2 = {"k_col_strided_bwd4": 16.0, "k_row_fused": 40.0, "k_col_strided_fwd1": 4.0, "k_col_mid": 20.0}
 # HBM bytes per launch from the PMC passes committed in profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
 # separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only known for the 4096^2 run
-PMC_KERNEL = {"k_col_strided_bwd4": "k_col_strided<64, 1>", "k_row_fused": "k_row<4096, 0, false>",
+PMC_KERNEL = {"k_col_strided_bwd4": "k_col_strided<64, 1>", "k_row_fused": "k_row8<false>",
               "k_col_strided_fwd1": "k_col_strided<64, -1>", "k_col_mid": "k_col_mid<64>"}
 
 
 def pmc_traffic(kernel, n):
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic_4096.json")
+    path = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic_4096.json")
     if n != 4096 or not os.path.exists(path):
         return None
     try:

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Copy the summaries of tools/profile_round.sh from gpurun_out/prof_<tag>/ into profiles/<tag>_*.
+usage: profile_collect.py <tag> [grid]"""
+import json, os, shutil, sys
+tag = sys.argv[1]; n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag); dst = os.path.join(root, "profiles")
+shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "%s_kernel_stats_%d.csv" % (tag, n)))
+line = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1]
+json.dump(json.loads(line), open(os.path.join(dst, "%s_bench_%d.json" % (tag, n)), "w"), indent=1)
+pmc = json.load(open(os.path.join(src, "pmc.json")))
+P = 16 * ((n // 2 + 1 + 15) // 16)
+C = 8 * n * P                                   # one complex field at the un-tuned pitch
+out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --cpu-steps 0 (%d^2, separate passes)" % n,
+       "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
+       "C_bytes": C, "kernels": {}}
+for k, v in pmc.items():
+    if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+        continue
+    b = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+    out["kernels"][k] = {"FETCH_SIZE_KB_avg": v["FETCH_SIZE"], "WRITE_SIZE_KB_avg": v["WRITE_SIZE"], "launches": v["launches"],
+                         "hbm_bytes_per_launch_corrected": b, "in_units_of_C": round(b / C, 2)}
+json.dump(out, open(os.path.join(dst, "%s_pmc_traffic_%d.json" % (tag, n)), "w"), indent=1, sort_keys=True)
+print(json.dumps({k: v["in_units_of_C"] for k, v in out["kernels"].items()}, indent=1))

@@ -363,8 +363,15 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
                 for (int e = 0; e < 16; ++e) {
                     const float u = -(reg[e].x * a.scale);            // main.cpp:200-201
                     const float v = reg[e].y * a.scale;               // main.cpp:214
-                    const float s = a.src ? a.src[(size_t)x * N + t_it + ord_i<RL>(e) * T] : 0.0f;
-                    const float val = -u * zx[e] - v * zy[e] + s;     // main.cpp:225-227
+                    reg[e].y = -u * zx[e] - v * zy[e];                // main.cpp:225-227 ...
+                }
+                if (a.src) {                                          // ... + vort_src; the loads and their wait stay in this branch
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) reg[e].y += a.src[(size_t)x * N + t_it + ord_i<RL>(e) * T];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float val = reg[e].y;
                     reg[e] = cf_make(t0[e], val);      // complete only after r == 1
                     t0[e] = val;
                 }
@@ -447,7 +454,7 @@ __global__ void __launch_bounds__(256) k_col_strided(ColArgs a)
         float4 in[W::NLA];
 #pragma unroll
         for (int m = 0; m < W::NLA; ++m) {
-            in[m] = ld4<(FB_NT & 1) != 0>(base + a.rm.off((g + 8 * m) * a.N2 + b, a.P) + 2 * cp);
+            in[m] = ld4<(FB_NT & 1) != 0 || (FB_NT_FWD && DIR < 0)>(base + a.rm.off((g + 8 * m) * a.N2 + b, a.P) + 2 * cp);
             access_gap(a.pace);
         }
         cf out[W::NLB];
@@ -458,7 +465,7 @@ __global__ void __launch_bounds__(256) k_col_strided(ColArgs a)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int k = h + 4 * s + W::R1 * q;
-                    st2<(FB_NT & 2) != 0>(&base[a.rm.off(k * a.N2 + b, a.P) + c], out[s * 8 + q]);
+                    st2<(FB_NT & 2) != 0 || (FB_NT_FWD && DIR < 0)>(&base[a.rm.off(k * a.N2 + b, a.P) + c], out[s * 8 + q]);
                     access_gap(a.pace);
                 }
         }
