@@ -24,11 +24,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 # algorithmic bytes per launch, in units of N^2 bytes (every 1-D pass over a field
 # reads + writes one N^2 float-equivalent array = 8 N^2 B; the x pass is two sub-pass kernels, each
 # credited half).  Sum over the four kernels of a stage = 80 N^2; x 4 stages = 320 N^2 per step.
-ALG_N2 = {"k_col_strided_bwd4": 16.0, "k_row_fused": 40.0, "k_col_strided_fwd1": 4.0, "k_col_mid": 20.0}
+ALG_N2 = {"k_col_strided_bwd4": 16.0, "k_row_fused": 40.0, "k_col_strided_fwd1": 4.0, "k_col_mid": 20.0,
+          "k_col_full": 40.0}      # the single-pass x transform does the work of the three column kernels
 # HBM bytes per launch from the PMC passes committed in profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
 # separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only known for the 4096^2 run
 PMC_KERNEL = {"k_col_strided_bwd4": "k_col_strided<64, 1>", "k_row_fused": "k_row8<false>",
-              "k_col_strided_fwd1": "k_col_strided<64, -1>", "k_col_mid": "k_col_mid<64>"}
+              "k_col_strided_fwd1": "k_col_strided<64, -1>", "k_col_mid": "k_col_mid<64>", "k_col_full": "k_col_full"}
 
 
 def pmc_traffic(kernel, n):
@@ -36,7 +37,11 @@ def pmc_traffic(kernel, n):
     if n != 4096 or not os.path.exists(path):
         return None
     try:
-        return json.load(open(path))["kernels"][PMC_KERNEL[kernel]]["hbm_bytes_per_launch_corrected"]
+        ks = json.load(open(path))["kernels"]
+        if kernel == "k_col_full":                  # four template instances (one per RK stage): average them
+            v = [d["hbm_bytes_per_launch_corrected"] for k, d in ks.items() if k.startswith("k_col_full")]
+            return sum(v) / len(v) if v else None
+        return ks[PMC_KERNEL[kernel]]["hbm_bytes_per_launch_corrected"]
     except (KeyError, ValueError):
         return None
 
@@ -159,6 +164,8 @@ def main():
         # per-kernel HIP-event timing over a second pass of the same K steps (events on the launch stream)
         prof = model.profile_steps(K)
         torch.cuda.synchronize()
+        if prof["k_col_strided_bwd4"][1] == 0 and prof["k_col_strided_fwd1"][1] == 0:     # single-pass x transform in use
+            prof = {"k_row_fused": prof["k_row_fused"], "k_col_full": prof["k_col_mid"]}
         per = {k: (ms / max(cnt, 1)) for k, (ms, cnt) in prof.items()}
         tot = {k: ms for k, (ms, cnt) in prof.items()}
         dom = max(tot, key=tot.get)

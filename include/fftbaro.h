@@ -152,9 +152,10 @@ int fb_model_info(fb_model *m, size_t *hbm_bytes, size_t *alg_bytes_per_step);
  * total_ms = wall time of the whole batch of steps on the device */
 int fb_model_time_steps(fb_model *m, int nsteps, float *total_ms);
 /* the same steps with a HIP-event pair around every kernel launch (on the model's stream).
- * Kernel classes: 0 = k_col_strided<+1> (4 fields, backward x sub-pass), 1 = k_row<FUSED>,
- * 2 = k_col_strided<-1> (tendency, forward x sub-pass), 3 = k_col_mid.  ms_sum[4] receives the
- * summed durations, launches[4] the launch counts. */
+ * Kernel classes: 0 = k_col_strided<+1> (4 fields, backward x sub-pass), 1 = the fused row pass,
+ * 2 = k_col_strided<-1> (tendency, forward x sub-pass), 3 = k_col_mid -- or, where the single-pass x
+ * transform is in use (nx = 4096 on one GPU), k_col_full, and classes 0 and 2 have no launches.
+ * ms_sum[4] receives the summed durations, launches[4] the launch counts. */
 int fb_model_profile_steps(fb_model *m, int nsteps, float *ms_sum, int *launches);
 
 /* ---------------------------------------------------------------------------------------

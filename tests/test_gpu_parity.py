@@ -301,27 +301,30 @@ def test_1000_steps_tolerance_1024(X, O, R):
     assert abs(np.linalg.norm(got.astype(np.float64)) / float(G["l2"]) - 1) < 1e-5
 
 
-def test_experimental_single_pass_x_transform(O, R):
-    """fb_col_full.h (opt-in with FB_FULL_PASS=1): one kernel for the whole x pass at nx = 4096.
-    Runs in a child process because the switch is read when the model is created."""
+def test_single_pass_x_transform_matches_three_kernel_path(O, R):
+    """fb_col_full.h (the default x pass at nx = 4096 on one GPU) against the three column kernels
+    (FB_FULL_PASS=0): same maths, different FFT factorisation.  Child processes because the switch is read
+    when the model is created."""
     import subprocess
     import sys
     code = (
         "import sys, numpy as np; sys.path[:0]=[%r, %r]\n"
         "import xlab_fftbarotropic_amd as X\n"
         "n=4096; v0=X.make_field('kuo2004', n)\n"
-        "m=X.Model(n,n,dt=0.75); m.set_vort(v0); m.step(2); np.save(sys.argv[1], m.vort().cpu().numpy()); np.save(sys.argv[2], m.spectrum().cpu().numpy())\n"
+        "m=X.Model(n,n,dt=0.75); m.set_vort(v0); m.step(3); np.save(sys.argv[1], m.vort().cpu().numpy()); np.save(sys.argv[2], m.spectrum().cpu().numpy())\n"
+        "p, u, v = m.diag(); np.save(sys.argv[3], u.cpu().numpy())\n"
     ) % (os.path.dirname(HERE), HERE)
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         outs = {}
         for flag in ("1", "0"):
             env = dict(os.environ, FB_FULL_PASS=flag)
-            a, b = os.path.join(d, "v%s.npy" % flag), os.path.join(d, "s%s.npy" % flag)
-            subprocess.check_call([sys.executable, "-c", code, a, b], env=env)
-            outs[flag] = (np.load(a), np.load(b))
+            a, b, cc = os.path.join(d, "v%s.npy" % flag), os.path.join(d, "s%s.npy" % flag), os.path.join(d, "u%s.npy" % flag)
+            subprocess.check_call([sys.executable, "-c", code, a, b, cc], env=env)
+            outs[flag] = (np.load(a), np.load(b), np.load(cc))
     assert R.rel_l2(outs["1"][0], outs["0"][0]) < 2e-6          # same maths, different FFT factorisation
     assert R.rel_l2(outs["1"][1].view(np.float32), outs["0"][1].view(np.float32)) < 2e-6
+    assert R.rel_l2(outs["1"][2], outs["0"][2]) < 2e-6
 
 
 def test_row8_matches_stockham_row_kernel(O, R):

@@ -30,7 +30,8 @@
 #define CF_X1_CF 16384                   /* cross-wave exchange: [k1][w][lane] complex             */
 #define CF_X2_STR 68                     /* in-wave exchange: [reg][l][c] with 4 complex pad / reg */
 #define CF_X2_CF (16 * 16 * CF_X2_STR)
-#define CF_LDS_CF (CF_X2_CF + 512)       /* + tabB[256] (W256^m) + tabA[256] (W4096^m, m < 256)    */
+#define CF_GX_CF 2048                    /* gradx_coe[4096] as floats                               */
+#define CF_LDS_CF (CF_X2_CF + 512 + CF_GX_CF)  /* + tabB[256] (W256^m) + tabA[256] (W4096^m, m < 256) + gradx_coe */
 #define CF_LDS_BYTES (CF_LDS_CF * 8)
 
 struct FullArgs {
@@ -41,6 +42,7 @@ struct FullArgs {
     long fstride;
     int P;                // pitch of the mixed arrays
     int ntiles;           // (ny/2)/8
+    int ntiles_active;    // tiles below this index hold at least one column inside the dealiasing circle; the rest are frozen (note N1)
     int stage;            // 0..3
     float nu, dt;
     SpecCoef coef;
@@ -163,14 +165,18 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf *lds = reinterpret_cast<cf *>(smem_raw);
     cf *tabB = lds + CF_X2_CF, *tabA = tabB + 256;
+    // gradx_coe in LDS: vmcnt counts loads and stores in order, so a coefficient read from global memory
+    // between two batches of stores would wait for the stores' acknowledgements (as k_col_mid used to)
+    float *gxt = reinterpret_cast<float *>(tabA + 256);
     const int tid = threadIdx.x, lane = tid & 63, l = lane >> 2, c = lane & 3;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave id, in an SGPR
     if (tid < 256) { tabB[tid] = a.tw256[tid]; tabA[tid] = a.tw4096[tid]; }
+    for (int i = tid; i < 4096; i += CF_THREADS) gxt[i] = a.coef.gx[i];
 
     // adjacent tiles on one XCD (blocks b and b+8 share an XCD: MI355X_MICROARCH.md, dispatch)
     int tile = blockIdx.x;
     if ((a.ntiles & 7) == 0) tile = (blockIdx.x & 7) * (a.ntiles >> 3) + (blockIdx.x >> 3);
-    if (tile >= a.ntiles) return;
+    if (tile >= a.ntiles_active) return;                  // frozen tile: state and derivatives stay what the priming pass left
 
     const int ky0 = tile * 8 + 2 * c;                                   // this thread's two columns: ky0, ky0+1
     const unsigned voff_m = (unsigned)((l * a.P + 2 * c) * (int)sizeof(cf));            // mixed arrays: row l of the wave's 16, column pair c
@@ -198,38 +204,68 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
          *ZO = reinterpret_cast<char *>(a.Zout) + ubase_s;
     const double ky2a = a.coef.ky2[ky0], ky2b = a.coef.ky2[ky0 + 1];
     const float gya = a.coef.gy[ky0], gyb = a.coef.gy[ky0 + 1];
-    const unsigned voff_kx = (unsigned)(16 * l);                 // kx = (w + 256 k3) [uniform] + 16 l
     constexpr int stage = STAGE;
     const float nu = a.nu, dt = a.dt, hdt = (stage == 2) ? a.dt : a.dt / 2.0f;
+    // The state arrays move in batches of two k3: the loads of batch b+1 are issued before the stores of batch b,
+    // so no load is ever queued right behind a store (whose acknowledgement it would have to wait for).
+    constexpr int KB = 1, NBATCH = 16 / KB;
+    float4 q0[KB], q1[KB], q2[KB], accp[KB];
+    auto load_batch = [&](int b) {
 #pragma unroll
-    for (int k3 = 0; k3 < 16; ++k3) {
-        const int ikx = w + 256 * k3 + 16 * l;
-        const double kx2 = (a.coef.kx2 + (w + 256 * k3))[voff_kx];
-        const float lapa = (float)(-(kx2 + ky2a)), lapb = (float)(-(kx2 + ky2b));
-        const float mska = coef_mask(a.coef, ikx, ky0), mskb = coef_mask(a.coef, ikx, ky0 + 1);
-        const float4 z0 = cf_ld4(Z0 + k3 * sstep, voff_s);
-        const float4 zc = stage == 0 ? z0 : cf_ld4(ZC + k3 * sstep, voff_s);
-        float4 k;
-        k.x = (v[0][k3].x + (zc.x * lapa) * nu) * mska; k.y = (v[0][k3].y + (zc.y * lapa) * nu) * mska;
-        k.z = (v[1][k3].x + (zc.z * lapb) * nu) * mskb; k.w = (v[1][k3].y + (zc.w * lapb) * nu) * mskb;
-        float4 acc, zn;
-        if (stage == 0) {
-            acc = k;
-            zn = make_float4(z0.x + k.x * hdt, z0.y + k.y * hdt, z0.z + k.z * hdt, z0.w + k.w * hdt);
-        } else if (stage < 3) {
-            const float4 ac = cf_ld4(AC + k3 * sstep, voff_s);
-            acc = make_float4(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y, ac.z + 2.0f * k.z, ac.w + 2.0f * k.w);
-            zn = make_float4(z0.x + k.x * hdt, z0.y + k.y * hdt, z0.z + k.z * hdt, z0.w + k.w * hdt);
-        } else {
-            const float4 ac = cf_ld4(AC + k3 * sstep, voff_s);
-            acc = ac;
-            zn = make_float4(z0.x + (ac.x + k.x) * dt / 6.0f, z0.y + (ac.y + k.y) * dt / 6.0f,
-                             z0.z + (ac.z + k.z) * dt / 6.0f, z0.w + (ac.w + k.w) * dt / 6.0f);
+        for (int j = 0; j < KB; ++j) {
+            const int k3 = b * KB + j;
+            q0[j] = cf_ld4(Z0 + k3 * sstep, voff_s);
+            if (stage != 0) { q1[j] = cf_ld4(ZC + k3 * sstep, voff_s); q2[j] = cf_ld4(AC + k3 * sstep, voff_s); }
         }
-        if (stage < 3) { cf_st4(AC + k3 * sstep, voff_s, acc); cf_st4(ZC + k3 * sstep, voff_s, zn); }
-        else cf_st4(ZO + k3 * sstep, voff_s, zn);
-        v[0][k3] = cf_make(zn.x, zn.y); v[1][k3] = cf_make(zn.z, zn.w);
-        if ((k3 & 1) == 1) CF_FENCE();
+    };
+    auto store_batch = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const int k3 = b * KB + j;
+            const float4 zn = make_float4(v[0][k3].x, v[0][k3].y, v[1][k3].x, v[1][k3].y);
+            if (stage < 3) { cf_st4(AC + k3 * sstep, voff_s, accp[j]); cf_st4(ZC + k3 * sstep, voff_s, zn); }
+            else cf_st4(ZO + k3 * sstep, voff_s, zn);
+        }
+    };
+    load_batch(0);
+#pragma unroll
+    for (int b = 0; b < NBATCH; ++b) {
+        float4 accn[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const int k3 = b * KB + j;
+            const int ikx = w + 256 * k3 + 16 * l;
+            const float gx = gxt[ikx];
+            const double kx2 = (double)gx * (double)gx;                      // fftwfop.cpp:42,45
+            const float lapa = (float)(-(kx2 + ky2a)), lapb = (float)(-(kx2 + ky2b));
+            const float mska = coef_mask(a.coef, ikx, ky0), mskb = coef_mask(a.coef, ikx, ky0 + 1);
+            const float4 z0 = q0[j];
+            const float4 zc = stage == 0 ? z0 : q1[j];
+            float4 k;
+            k.x = (v[0][k3].x + (zc.x * lapa) * nu) * mska; k.y = (v[0][k3].y + (zc.y * lapa) * nu) * mska;
+            k.z = (v[1][k3].x + (zc.z * lapb) * nu) * mskb; k.w = (v[1][k3].y + (zc.w * lapb) * nu) * mskb;
+            float4 acc, zn;
+            if (stage == 0) {
+                acc = k;
+                zn = make_float4(z0.x + k.x * hdt, z0.y + k.y * hdt, z0.z + k.z * hdt, z0.w + k.w * hdt);
+            } else if (stage < 3) {
+                const float4 ac = q2[j];
+                acc = make_float4(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y, ac.z + 2.0f * k.z, ac.w + 2.0f * k.w);
+                zn = make_float4(z0.x + k.x * hdt, z0.y + k.y * hdt, z0.z + k.z * hdt, z0.w + k.w * hdt);
+            } else {
+                const float4 ac = q2[j];
+                acc = ac;
+                zn = make_float4(z0.x + (ac.x + k.x) * dt / 6.0f, z0.y + (ac.y + k.y) * dt / 6.0f,
+                                 z0.z + (ac.z + k.z) * dt / 6.0f, z0.w + (ac.w + k.w) * dt / 6.0f);
+            }
+            accn[j] = acc;
+            v[0][k3] = cf_make(zn.x, zn.y); v[1][k3] = cf_make(zn.z, zn.w);
+        }
+        if (b + 1 < NBATCH) load_batch(b + 1);
+#pragma unroll
+        for (int j = 0; j < KB; ++j) accp[j] = accn[j];
+        store_batch(b);
+        CF_FENCE();
     }
 
     // ---- four derivatives of the new state, each transformed back and stored (fftwfop.cpp:87-117)
@@ -245,17 +281,17 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
             }
         }
         const bool psi = f >= 2, use_gx = (f == 0 || f == 3);
-        const unsigned vkx = (unsigned)launder((int)voff_kx);     // per-iteration copy: keeps the coefficient loads inside the loop
+        const int lkx = launder(16 * l);                          // per-iteration copy: keeps the table addresses inside the loop
 #pragma unroll
         for (int k3 = 0; k3 < 16; ++k3) {
             cf za = v[0][k3], zb = v[1][k3];
+            const float gx = gxt[w + 256 * k3 + lkx];
             if (psi) {                                // psi_c = invertLaplacian(vort_c)   main.cpp:179
-                const double kx2 = (a.coef.kx2 + (w + 256 * k3))[vkx];
+                const double kx2 = (double)gx * (double)gx;
                 const float lia = (w + 256 * k3 + 16 * l == 0 && ky0 == 0) ? 1.0f : (float)(-(kx2 + ky2a));
                 const float lib = (float)(-(kx2 + ky2b));
                 za = cf_make(za.x / lia, za.y / lia); zb = cf_make(zb.x / lib, zb.y / lib);
             }
-            const float gx = (a.coef.gx + (w + 256 * k3))[vkx];
             const float ka = use_gx ? gx : gya, kb = use_gx ? gx : gyb;
             v[0][k3] = cf_make(-za.y * ka, za.x * ka);
             v[1][k3] = cf_make(-zb.y * kb, zb.x * kb);
