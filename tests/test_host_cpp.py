@@ -91,6 +91,39 @@ def test_driver_outputs_match_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_driver_4096_default_path(tmp_path):
+    """The drop-in driver on the benchmark grid (4096^2 Kuo2004, dt = 0.75 s): there the engine takes its
+    single-pass x transform and the digit-permutation row kernel, and the record path (get_vort / get_diag)
+    converts from that path's private state layout.  Against the Python binding on the same library (bit for
+    bit) and the oracle after 2 steps."""
+    import oracle_py as O
+    import ref_numpy as R
+    import xlab_fftbarotropic_amd as X
+    _build()
+    n = 4096
+    (tmp_path / "input").mkdir()
+    (tmp_path / "output").mkdir()
+    v0 = O.make_field("kuo2004", n)
+    v0.tofile(str(tmp_path / "input" / "initial_vorticity.bin"))
+    subprocess.run([os.path.join(HOST, "barotropic_main.out"), "--npts", str(n), "--steps", "3", "--record-step", "2",
+                    "--dt", "0.75"], cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    rd = lambda name: np.fromfile(str(tmp_path / "output" / name), dtype="<f4").reshape(n, n)
+    m = X.Model(n, n, dt=0.75)
+    m.set_vort(v0)
+    m.step(2)
+    psi, u, v = m.diag()
+    assert np.array_equal(rd("vort_step_2.bin"), m.vort().cpu().numpy())
+    assert np.array_equal(rd("psi_step_2.bin"), psi.cpu().numpy())
+    assert np.array_equal(rd("u_step_2.bin"), u.cpu().numpy())
+    assert np.array_equal(rd("v_step_2.bin"), v.cpu().numpy())
+    mo = O.Model(n, n, dt=0.75)
+    mo.set_vort(v0)
+    mo.step(2)
+    po, uo, vo = mo.diag()
+    assert R.rel_l2(rd("vort_step_2.bin"), mo.vort()) < 1e-5
+    assert R.rel_l2(rd("u_step_2.bin"), uo) < 1e-5 and R.rel_l2(rd("psi_step_2.bin"), po) < 1e-5
+
+
 def test_driver_fifo_source(tmp_path):
     """main-shallow-water.cpp path: per step one flag byte, GRIDS float32 after a flag of 1
     (vorticity_source.cpp:112-133); the producer closes early so the last reads hit EOF."""
