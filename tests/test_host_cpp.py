@@ -124,6 +124,7 @@ def test_driver_4096_default_path(tmp_path):
     assert R.rel_l2(rd("u_step_2.bin"), uo) < 1e-5 and R.rel_l2(rd("psi_step_2.bin"), po) < 1e-5
 
 
+@pytest.mark.gpu
 def test_driver_fifo_source(tmp_path):
     """main-shallow-water.cpp path: per step one flag byte, GRIDS float32 after a flag of 1
     (vorticity_source.cpp:112-133); the producer closes early so the last reads hit EOF."""
