@@ -327,6 +327,24 @@ def test_single_pass_x_transform_matches_three_kernel_path(O, R):
     assert R.rel_l2(outs["1"][2], outs["0"][2]) < 2e-6
 
 
+def test_single_pass_x_transform_with_long_rows(X, O, R):
+    """nx = 4096, ny = 8192: the single-pass x transform with two tiles per CU (512 tiles) next to the Stockham
+    row kernel of the long rows -- a combination no square grid exercises.  Two steps against the oracle."""
+    nx, ny = 4096, 8192
+    rng = np.random.default_rng(11)
+    v0 = (1e-3 * rng.standard_normal((nx, ny))).astype(np.float32)
+    v0 = O.c2r(O.Operators(nx, ny, L, L).dealiase(O.r2c(v0)), ny) / np.float32(nx * ny)
+    m = X.Model(nx, ny, dt=0.375)
+    m.set_vort(v0)
+    mo = O.Model(nx, ny, dt=0.375)
+    mo.set_vort(v0)
+    m.step(2)
+    mo.step(2)
+    assert R.rel_l2(m.vort().cpu().numpy(), mo.vort()) < 1e-5
+    s = m.spectrum().cpu().numpy()
+    assert np.isfinite(s.view(np.float32)).all()
+
+
 def test_row8_matches_stockham_row_kernel(O, R):
     """fb_row8.h (default at ny = 4096) against the Stockham row kernel (FB_NO_ROW8=1): same maths, different
     factorisation and physical-space ordering -- with a vorticity source, whose gather follows that ordering.
