@@ -1,9 +1,11 @@
-// fb_col_full.h -- single-pass x-transform + spectral update for nx = 4096 (one GPU).
+// fb_col_full.h -- single-pass x-transform + spectral update for nx = 4096 (one GPU); the default there.
 //
 // Replaces the three column kernels of a stage (k_col_strided<-1>, k_col_mid, k_col_strided<+1>:
-// 20 C of HBM traffic) by one kernel that moves 10 C: a 1024-thread workgroup keeps a whole tile of
-// 8 ky-columns x 4096 x-rows (256 KiB) in its registers and runs the length-4096 transforms as
-// 16 x 16 x 16 with one cross-wave and one in-wave LDS exchange per transform.
+// 17.5 C of measured traffic) by one kernel that moves 11.3-13.7 C: a 1024-thread workgroup keeps a whole
+// tile of 8 ky-columns x 4096 x-rows (256 KiB) in its registers and runs the length-4096 transforms as
+// 16 x 16 x 16 with one cross-wave and one in-wave LDS exchange per transform.  Same arithmetic as k_col_mid
+// (main.cpp:148,179,198,212,237,240-251,296-312; fftwfop.cpp:87-124) with a different FFT factorisation.
+// Measured at 4096^2: 0.163 ms per stage against 0.21 ms for the three kernels (DESIGN.md sections 4, 7).
 //
 //   thread (w = wave 0..15, l = (lane>>2) 0..15, c = lane&3) holds, for columns 2c,2c+1 of the tile:
 //     mixed space   : rows x = 256 i + 16 w + l,            register index i  = 0..15
@@ -19,7 +21,8 @@
 // The ky = ny/2 column is not handled here: on square grids it lies outside the dealiasing circle
 // (fftwfop.cpp:57-61), so its tendency is always masked, its state never changes (SURVEY note N1)
 // and its four derivative columns in W4 stay what the priming pass wrote.  That makes the column
-// count a power of two (ny/2 = 256 tiles of 8 at 4096^2: one tile per CU, no tail).
+// count a power of two (ny/2 = 256 tiles of 8 at 4096^2: one tile per CU, no tail).  Tiles that lie
+// entirely outside the circle (ky >= 1936 at 4096^2) are skipped for the same reason.
 //
 // State arrays (ZA, ZB, ACC) use a layout private to this kernel:
 //   [tile][k3][thread] float4 = (column 2c, column 2c+1)   -- fully coalesced, 16 B per lane.
