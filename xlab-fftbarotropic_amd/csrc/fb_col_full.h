@@ -60,7 +60,7 @@ FB_DEV void cf_xchg_waves(cf *lds, cf *v, int w, int lane)
     for (int r = 0; r < 16; ++r) lds[(r * 16 + w) * 64 + lane] = v[r];
     lds_barrier();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = lds[(w * 16 + r) * 64 + lane];
+    for (int r = 0; r < 16; ++r) v[r] = lds_rd(&lds[(w * 16 + r) * 64 + lane]);
     lds_barrier();
 }
 
@@ -73,7 +73,7 @@ FB_DEV void cf_xchg_lanes(cf *lds, cf *v, int w, int l, int c)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-local: DS ops of a wave are in order
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = reg[l * CF_X2_STR + r * 4 + c];
+    for (int r = 0; r < 16; ++r) v[r] = lds_rd(&reg[l * CF_X2_STR + r * 4 + c]);
     lds_barrier();                                           // region is reused by the other waves next
 }
 

@@ -44,7 +44,7 @@ FB_DEV void r8_xch_group(cf *v, cf *xbuf, int w, int l)
     for (int p = 0; p < 8; ++p) xbuf[p * Row8::SLICE + w * 64 + l] = v[p];
     lds_barrier();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = xbuf[w * Row8::SLICE + e * 64 + l];
+    for (int e = 0; e < 8; ++e) v[e] = lds_rd(&xbuf[w * Row8::SLICE + e * 64 + l]);
 }
 // swap the register index with l_hi (HI) or l_lo (!HI) inside the wave's own slice
 template <bool HI> FB_DEV void r8_xch_wave(cf *v, cf *slice, int l_hi, int l_lo)
@@ -59,7 +59,7 @@ template <bool HI> FB_DEV void r8_xch_wave(cf *v, cf *slice, int l_hi, int l_lo)
     __builtin_amdgcn_wave_barrier();
     const cf *rd = HI ? slice + l_hi * PITCH + l_lo : slice + l_lo * PITCH + l_hi * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = rd[e * (HI ? 8 : 1)];
+    for (int e = 0; e < 8; ++e) v[e] = lds_rd(&rd[e * (HI ? 8 : 1)]);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -145,12 +145,12 @@ FB_DEV void r8_ext(cf *v, int t, const cf *stg)
     for (int e = 0; e < 8; ++e) {
         if (e < 4) {
             const int k = t + e * T;
-            const cf a = stg[k], b = stg[N / 2 + k];
+            const cf a = lds_rd(&stg[k]), b = lds_rd(&stg[N / 2 + k]);
             v[e] = (e == 0 && t == 0) ? cf_make(a.x, b.x) : cf_make(a.x - b.y, a.y + b.x);
         } else {
             const int k = (8 - e) * T - t;                         // mirror, in (0, N/2]
             const bool nyq = (e == 4 && t == 0);                   // k = N/2: the Nyquist slots behind the two rows
-            const cf a = stg[nyq ? N : k], b = stg[nyq ? N + 1 : N / 2 + k];
+            const cf a = lds_rd(&stg[nyq ? N : k]), b = lds_rd(&stg[nyq ? N + 1 : N / 2 + k]);
             v[e] = nyq ? cf_make(a.x, b.x) : cf_make(a.x + b.y, b.x - a.y);
         }
     }
