@@ -222,7 +222,7 @@ FB_DEV void row_store_pair(cf *lds, int t, const cf *reg, bool valid, cf *T_, in
         if (i < 8) {
             const int k = t + i * T;
             const cf zk = reg[e];
-            const cf zn = (i == 0 && t == 0) ? zk : lds[lds_pad(N - k - HOFF)];
+            const cf zn = (i == 0 && t == 0) ? zk : lds_rd(&lds[lds_pad(N - k - HOFF)]);
             st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, k)), cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)));
             st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, k)), cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)));
         } else if (i == 8 && t == 0) {                       // Nyquist: its own mirror
@@ -262,13 +262,13 @@ FB_DEV void row_ext_from_stage(cf *reg, int t, const cf *stg, cf nyqA, cf nyqB)
         const int i = ord_i<R0>(e);
         if (i < 8) {
             const int k = t + i * T;
-            const cf a = stg[k], b = stg[N / 2 + k];
+            const cf a = lds_rd(&stg[k]), b = lds_rd(&stg[N / 2 + k]);
             reg[e] = (i == 0 && t == 0) ? cf_make(a.x, b.x) : cf_make(a.x - b.y, a.y + b.x);
         } else {
             int k = (16 - i) * T - t;
             const bool nyq = (i == 8 && t == 0);
             if (nyq) k = 0;
-            cf a = stg[k], b = stg[N / 2 + k];
+            cf a = lds_rd(&stg[k]), b = lds_rd(&stg[N / 2 + k]);
             reg[e] = nyq ? cf_make(nyqA.x, nyqB.x) : cf_make(a.x + b.y, b.x - a.y);
         }
     }
