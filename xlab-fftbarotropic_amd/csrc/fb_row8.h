@@ -81,7 +81,7 @@ FB_DEV void r8_bwd(cf *v, cf *xbuf, const Row8Tw &tw, int w, int l)
     r8_xch_wave<true>(v, slice, l_hi, l_lo);
     Bfly<8, +1>::run(v);
 #pragma unroll
-    for (int p = 1; p < 8; ++p) v[p] = cmulc(v[p], tw.w2[p * 8 + l_lo]);
+    for (int p = 1; p < 8; ++p) v[p] = cmulc(v[p], lds_rd(&tw.w2[p * 8 + l_lo]));
     r8_xch_wave<false>(v, slice, l_hi, l_lo);
     Bfly<8, +1>::run(v);
 }
@@ -93,7 +93,7 @@ FB_DEV void r8_fwd(cf *v, cf *xbuf, const Row8Tw &tw, int w, int l)
     Bfly<8, -1>::run(v);
     r8_xch_wave<false>(v, slice, l_hi, l_lo);
 #pragma unroll
-    for (int p = 1; p < 8; ++p) v[p] = cmul(v[p], tw.w2[p * 8 + l_lo]);
+    for (int p = 1; p < 8; ++p) v[p] = cmul(v[p], lds_rd(&tw.w2[p * 8 + l_lo]));
     Bfly<8, -1>::run(v);
     r8_xch_wave<true>(v, slice, l_hi, l_lo);
 #pragma unroll
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(512, 4) k_row8(RowArgs a, const cf *__restrict
             for (int e = 0; e < 4; ++e) {
                 const int k = tt + e * T;
                 const cf zk = v[e];
-                const cf zn = (e == 0 && tt == 0) ? zk : xbuf[N / 2 - k];            // Z[N - k] sits at N - k - N/2
+                const cf zn = (e == 0 && tt == 0) ? zk : lds_rd(&xbuf[N / 2 - k]);            // Z[N - k] sits at N - k - N/2
                 st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(a.T, a.ks, a.t_sstride, x0, k)), cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)));
                 st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(a.T, a.ks, a.t_sstride, x1, k)), cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)));
             }
