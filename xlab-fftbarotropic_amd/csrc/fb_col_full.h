@@ -64,7 +64,10 @@ FB_DEV void cf_xchg_waves(cf *lds, cf *v, int w, int lane)
     lds_barrier();
 }
 
-// 16x16 transpose between l = lane>>2 and the register index, inside each wave's own LDS region
+// 16x16 transpose between l = lane>>2 and the register index, inside each wave's own LDS region.  The region
+// is private (DS operations of a wave execute in order), so a workgroup barrier is needed only where the next
+// LDS user is the cross-wave exchange, whose layout overlaps the other waves' regions (SYNC).
+template <bool SYNC>
 FB_DEV void cf_xchg_lanes(cf *lds, cf *v, int w, int l, int c)
 {
     cf *reg = lds + w * (16 * CF_X2_STR);
@@ -74,7 +77,8 @@ FB_DEV void cf_xchg_lanes(cf *lds, cf *v, int w, int l, int c)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = lds_rd(&reg[l * CF_X2_STR + r * 4 + c]);
-    lds_barrier();                                           // region is reused by the other waves next
+    if (SYNC) lds_barrier();                                 // the cross-wave exchange comes next
+    else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 }
 
 // The two columns go through every step one after the other, fenced with sched_barrier: letting
@@ -128,7 +132,7 @@ FB_DEV void cf_fft4096(cf *lds, const cf *tabA, const cf *tabB, cf (*v)[16], int
             v[col][0] = cmul(v[col][0], a);
 #pragma unroll
             for (int k2 = 1; k2 < 16; ++k2) { v[col][k2] = cmul(v[col][k2], cmul(a, tabB[l * k2])); if ((k2 & 3) == 3) CF_FENCE(); }
-            cf_xchg_lanes(lds, v[col], w, l, c);                             // now l = k2, reg = l
+            cf_xchg_lanes<false>(lds, v[col], w, l, c);                      // now l = k2, reg = l
             CF_FENCE();
         }
 #pragma unroll
@@ -140,7 +144,8 @@ FB_DEV void cf_fft4096(cf *lds, const cf *tabA, const cf *tabB, cf (*v)[16], int
             cf_bfly16<+1>(v[col]);                                       // over k3 -> l (in reg)
 #pragma unroll
             for (int lr = 1; lr < 16; ++lr) { v[col][lr] = cmulc(v[col][lr], cmul(tabA[lr * w], tabB[lr * l])); if ((lr & 3) == 3) CF_FENCE(); }
-            cf_xchg_lanes(lds, v[col], w, l, c);                             // now lane-l = l, reg = k2
+            if (col == 0) cf_xchg_lanes<false>(lds, v[col], w, l, c);        // now lane-l = l, reg = k2
+            else cf_xchg_lanes<true>(lds, v[col], w, l, c);
             CF_FENCE();
         }
 #pragma unroll
