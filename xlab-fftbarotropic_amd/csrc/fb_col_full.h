@@ -57,7 +57,7 @@ struct FullArgs {
 FB_DEV void cf_xchg_waves(cf *lds, cf *v, int w, int lane)
 {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) lds[(r * 16 + w) * 64 + lane] = v[r];
+    for (int r = 0; r < 16; ++r) lds_wr(&lds[(r * 16 + w) * 64 + lane], v[r]);
     lds_barrier();
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = lds_rd(&lds[(w * 16 + r) * 64 + lane]);
@@ -72,7 +72,7 @@ FB_DEV void cf_xchg_lanes(cf *lds, cf *v, int w, int l, int c)
 {
     cf *reg = lds + w * (16 * CF_X2_STR);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) reg[r * CF_X2_STR + l * 4 + c] = v[r];
+    for (int r = 0; r < 16; ++r) lds_wr(&reg[r * CF_X2_STR + l * 4 + c], v[r]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-local: DS ops of a wave are in order
     __builtin_amdgcn_wave_barrier();
 #pragma unroll

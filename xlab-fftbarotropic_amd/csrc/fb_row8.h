@@ -41,7 +41,7 @@ FB_DEV void r8_xch_group(cf *v, cf *xbuf, int w, int l)
 #endif
     lds_barrier();                                    // every wave is done with its slice
 #pragma unroll
-    for (int p = 0; p < 8; ++p) xbuf[p * Row8::SLICE + w * 64 + l] = v[p];
+    for (int p = 0; p < 8; ++p) lds_wr(&xbuf[p * Row8::SLICE + w * 64 + l], v[p]);
     lds_barrier();
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = lds_rd(&xbuf[w * Row8::SLICE + e * 64 + l]);
@@ -55,7 +55,7 @@ template <bool HI> FB_DEV void r8_xch_wave(cf *v, cf *slice, int l_hi, int l_lo)
     constexpr int PITCH = HI ? Row8::PITCH_HI : Row8::PITCH_LO;
     cf *wr = slice + l_hi * 8 + l_lo;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) wr[e * PITCH] = v[e];
+    for (int e = 0; e < 8; ++e) lds_wr(&wr[e * PITCH], v[e]);
     __builtin_amdgcn_wave_barrier();
     const cf *rd = HI ? slice + l_hi * PITCH + l_lo : slice + l_lo * PITCH + l_hi * 8;
 #pragma unroll
