@@ -450,8 +450,8 @@ FB_DEV void stockham_stage(cf *lds, int t, const SRC &src, cf *reg /*[16]*/)
             cf *wb = lds + lds_pad(j0);
 #pragma unroll
             for (int q = 0; q < R; ++q) {
-                if (WR_LIN) wb[q * NS + (q * NS) / 16] = reg[m * R + q];
-                else lds[lds_pad(j0 + q * NS)] = reg[m * R + q];
+                if (WR_LIN) lds_wr(&wb[q * NS + (q * NS) / 16], reg[m * R + q]);
+                else lds_wr(&lds[lds_pad(j0 + q * NS)], reg[m * R + q]);
             }
         }
         lds_barrier();
