@@ -33,7 +33,7 @@ PMC_KERNEL = {"k_col_strided_bwd4": "k_col_strided<64, 1>", "k_row_fused": "k_ro
 
 
 def pmc_traffic(kernel, n):
-    path = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic_4096.json")
+    path = os.path.join(ROOT, "profiles", "r01_i_pmc_traffic_4096.json")
     if n != 4096 or not os.path.exists(path):
         return None
     try:
