@@ -190,8 +190,6 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
     float *gxt = reinterpret_cast<float *>(tabA + 256);
     const int tid = threadIdx.x, lane = tid & 63, l = lane >> 2, c = lane & 3;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave id, in an SGPR
-    if (tid < 256) { tabB[tid] = a.tw256[tid]; tabA[tid] = a.tw4096[tid]; }
-    for (int i = tid; i < 4096; i += CF_THREADS) gxt[i] = a.coef.gx[i];
 
     // adjacent tiles on one XCD (blocks b and b+8 share an XCD: MI355X_MICROARCH.md, dispatch)
     int tile = blockIdx.x;
@@ -207,13 +205,19 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
     const size_t sstep = (size_t)CF_THREADS * sizeof(float4);
 
     cf v[2][16];
-    {   // ---- tendency tile -> registers (rows 256 i + 16 w + l)
+    {   // ---- tendency tile -> registers (rows 256 i + 16 w + l); the tables are filled while these loads travel
         const char *src = reinterpret_cast<const char *>(a.Tin) + ubase_m;
+        float4 tin[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float4 t = ld4<CF_NT_TIN != 0>(src + i * rstep + voff_m);
-            v[0][i] = cf_make(t.x, t.y); v[1][i] = cf_make(t.z, t.w);
-        }
+        for (int i = 0; i < 16; ++i) tin[i] = ld4<CF_NT_TIN != 0>(src + i * rstep + voff_m);
+        float g4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g4[i] = a.coef.gx[tid + i * CF_THREADS];
+        if (tid < 256) { tabB[tid] = a.tw256[tid]; tabA[tid] = a.tw4096[tid]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gxt[tid + i * CF_THREADS] = g4[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { v[0][i] = cf_make(tin[i].x, tin[i].y); v[1][i] = cf_make(tin[i].z, tin[i].w); }
     }
     __syncthreads();                                            // twiddle tables are in LDS
     cf_fft4096<-1>(lds, tabA, tabB, v, w, l, c, lane);           // main.cpp:237 (x part)
