@@ -21,7 +21,7 @@ def test_host_programs_link():
     import xlab_fftbarotropic_amd as X
     X.build_lib()
     _build()
-    for exe in ("barotropic_main.out", "shim_check.out", "invert_pres.out", "vort_src_input.out"):
+    for exe in ("barotropic_main.out", "shim_check.out", "invert_pres.out", "vort_src_input.out", "find_min.out", "fftw_shape_check.out"):
         assert os.access(os.path.join(HOST, exe), os.X_OK)
 
 
@@ -245,3 +245,152 @@ def test_driver_restart_with_start_step(tmp_path):
         "%s_step_%d.bin" % (nm, s) for s in (100, 200) for nm in ("vort_src_input", "vort", "psi", "u", "v"))
     rd = lambda d, f: np.fromfile(str(tmp_path / d / "output" / f), dtype="<f4")
     assert R.rel_l2(rd("b", "vort_step_200.bin"), rd("a", "vort_step_200.bin")) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# boundary fidelity: the reference's own link names (fieldio.hpp:5-6, <fftw3.h>) resolved by the product
+# ---------------------------------------------------------------------------------------------------
+LIBDIR = os.path.join(ROOT, "xlab-fftbarotropic_amd", "lib")
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+
+_FIELDIO_CHILD = r"""
+import ctypes, sys, numpy as np
+lib = ctypes.CDLL(sys.argv[1])
+wr, rd = getattr(lib, "_Z10writeFieldPKcPfm"), getattr(lib, "_Z9readFieldPKcPfm")
+for fn in (wr, rd):
+    fn.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t]; fn.restype = None
+a = np.random.default_rng(7).standard_normal(12345).astype(np.float32)
+fp = lambda x: x.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+wr(b"field.bin", fp(a), a.size)
+b = np.zeros_like(a); rd(b"field.bin", fp(b), b.size)
+assert np.array_equal(a, b)
+short = np.zeros(20000, np.float32); rd(b"field.bin", fp(short), short.size)      # short read: fieldio.cpp:26 stays silent
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "libfieldio.so")), reason="oracle/_ref not built")
+def test_product_fieldio_library_matches_reference_library(tmp_path):
+    """lib/libfieldio.so (csrc/fb_fieldio.cpp) exports the reference's mangled writeField/readField (fieldio.hpp:5-6)
+    and behaves byte for byte like the reference's own fieldio.cpp compiled into oracle/_ref: same file, same
+    stderr lines, including the short read that reports the element count as "bytes" (fieldio.cpp:32)."""
+    import sys
+    import xlab_fftbarotropic_amd as X
+    X.build_lib()
+    outs = {}
+    for tag, lib in (("ref", os.path.join(REFDIR, "libfieldio.so")), ("mine", os.path.join(LIBDIR, "libfieldio.so")),
+                     ("abi", os.path.join(LIBDIR, "libfftbaro.so"))):
+        d = tmp_path / tag
+        d.mkdir()
+        res = subprocess.run([sys.executable, "-c", _FIELDIO_CHILD, lib], cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             check=True)
+        outs[tag] = (open(str(d / "field.bin"), "rb").read(), res.stderr)
+    assert outs["mine"][0] == outs["ref"][0] and outs["abi"][0] == outs["ref"][0] and len(outs["ref"][0]) == 4 * 12345
+    assert outs["mine"][1] == outs["ref"][1] == b"Output field.bin\n12345 bytes read: field.bin\n12345 bytes read: field.bin\n"
+    assert outs["abi"][1] == outs["ref"][1]
+
+
+def test_fftw_shim_exports_every_declared_name():
+    """lib/libfftw3f_fb.so exports the FFTW3 names include/fftw3_fb.h declares (main.cpp:103-135,154)."""
+    import ctypes
+    import re
+    import xlab_fftbarotropic_amd as X
+    X.lib()                                              # libfftbaro.so (and torch's HIP runtime) first
+    src = open(os.path.join(ROOT, "include", "fftw3_fb.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(fftwf_[a-z0-9_]+)\s*\(", src)))
+    assert {"fftwf_malloc", "fftwf_free", "fftwf_plan_dft_r2c_2d", "fftwf_plan_dft_c2r_2d", "fftwf_execute", "fftwf_destroy_plan"} <= set(names)
+    L = ctypes.CDLL(os.path.join(LIBDIR, "libfftw3f_fb.so"))
+    assert not [n for n in names if not hasattr(L, n)]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "find_min.out")), reason="oracle/_ref not built")
+def test_find_min_matches_reference_build(tmp_path):
+    """host/find_min.cpp against the reference's find_min.cpp:67-101 compiled from its own source (grid fixed at
+    768^2 there): same 30 lines in the same (replacement) order, ties and all; also under ASan/UBSan."""
+    import oracle_py as O
+    _build()
+    subprocess.check_call(["make", "-s", "-C", HOST, "asan"])
+    n = 768
+    rng = np.random.default_rng(3)
+    f = (O.make_field("kuo2004", n) * np.float32(-1e3)).astype(np.float32)
+    f += rng.integers(0, 4, size=(n, n)).astype(np.float32) * np.float32(1e-3)          # many exact ties
+    names = []
+    for i in range(2):
+        (f + np.float32(i)).astype(np.float32).tofile(str(tmp_path / ("pres_%d.bin" % i)))
+        names.append("pres_%d.bin" % i)
+    inp = "\n".join(names) + "\n"
+    run = lambda cmd: subprocess.run(cmd, cwd=str(tmp_path), input=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
+    ref = run([os.path.join(REFDIR, "find_min.out")])
+    mine = run([os.path.join(HOST, "find_min.out"), "--npts", str(n)])
+    asan = run([os.path.join(HOST, "asan", "find_min.out"), "--npts", str(n)])
+    assert mine.stdout == ref.stdout and len(ref.stdout.splitlines()) == 60
+    assert mine.stderr == ref.stderr
+    assert asan.stdout == ref.stdout and "ERROR" not in asan.stderr and "runtime error" not in asan.stderr
+    ix, iy, val = ref.stdout.splitlines()[0].split()
+    assert float(val) == pytest.approx(float(f[int(ix), int(iy)]), rel=1e-5)
+
+
+def test_fifo_producer_under_asan():
+    """host/vort_src_input.cpp + csrc/fb_fields.cpp under AddressSanitizer/UBSan (GPU ASan is unavailable on this pool)."""
+    subprocess.check_call(["make", "-s", "-C", HOST, "asan"])
+    raw = subprocess.run([os.path.join(HOST, "asan", "vort_src_input.out"), "--npts", "64", "--dt", "3", "--steps", "12", "--beg-time", "9",
+                          "--duration", "12"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    assert len(raw.stdout) == 11 + 2 * 64 * 64 * 4 and b"ERROR" not in raw.stderr and b"runtime error" not in raw.stderr
+
+
+@pytest.mark.gpu
+def test_fftw_shaped_translation_unit_matches_oracle(tmp_path):
+    """host/fftw_shape_check.cpp: the reference's call lines (#include <fftw3.h>, fftwf_malloc, fftwf_plan_dft_r2c_2d(XPTS, YPTS,
+    in, out, FFTW_ESTIMATE), fftwf_execute, readField/writeField, fop.gradx(...), host loops) linked against
+    -lfftw3f_fb -lfieldio: rk1_c of main.cpp:146-244,296 against the oracle."""
+    import oracle_py as O
+    import ref_numpy as R
+    _build()
+    n = 256
+    v0 = O.make_field("elliptic", n)
+    (tmp_path / "input").mkdir()
+    v0.tofile(str(tmp_path / "input" / "initial_vorticity.bin"))
+    out = str(tmp_path / "rk1.bin")
+    res = subprocess.run([os.path.join(HOST, "fftw_shape_check.out"), str(tmp_path / "input" / "initial_vorticity.bin"), out],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, text=True)
+    assert "%d bytes read" % (n * n) in res.stderr and "Output %s" % out in res.stderr
+    got = np.fromfile(out, dtype="<f4")
+    ops = O.Operators(n, n, 6e5, 6e5)
+    vc = O.r2c(v0)
+    g = np.float32(n * n)
+    dzdx = O.c2r(ops.gradx(vc), n) / g
+    dzdy = O.c2r(ops.grady(vc), n) / g
+    psi = ops.invertLaplacian(vc)
+    u = -(O.c2r(ops.grady(psi), n) / g)
+    v = O.c2r(ops.gradx(psi), n) / g
+    t = -u * dzdx - v * dzdy
+    tc = O.r2c(t)
+    tc = (tc.view(np.float32) + ops.laplacian(vc).view(np.float32) * np.float32(6.5)).view(np.complex64)
+    want = ops.dealiase(tc).view(np.float32).ravel()
+    assert R.rel_l2(got, want) < 1e-5
+
+
+@pytest.mark.gpu
+def test_record_files_have_the_plotting_layout(tmp_path):
+    """test/01-runtest/plot/draw_figs.py:103-105 reads every dump as np.fromfile('<f4', count=nx*ny).reshape((nx, ny)).transpose():
+    index [i = x][j = y] on disk (configuration.hpp:31), image rows = y after the transpose.  Kuo2004's weak vortex sits
+    50 km to the +x side of the strong one (makefield-Kuo2004.cpp:35-38), which only shows up on the right axis."""
+    _build()
+    n = 256
+    import oracle_py as O
+    (tmp_path / "input").mkdir()
+    (tmp_path / "output").mkdir()
+    O.make_field("kuo2004", n).tofile(str(tmp_path / "input" / "initial_vorticity.bin"))
+    subprocess.check_call([os.path.join(HOST, "barotropic_main.out"), "--npts", str(n), "--steps", "1"], cwd=str(tmp_path),
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    L, dx = 6e5, 6e5 / n
+    for name in ("vort", "u", "v", "psi", "vort_src_input"):
+        assert os.path.getsize(str(tmp_path / "output" / ("%s_step_0.bin" % name))) == 4 * n * n
+    img = np.fromfile(str(tmp_path / "output" / "vort_step_0.bin"), dtype="<f4", count=n * n).reshape((n, n)).transpose()
+    iy, ix = np.unravel_index(np.argmax(img), img.shape)                  # image[row = y][col = x]
+    assert abs(ix - (L / 2) / dx) <= 1 and abs(iy - (L / 2) / dx) <= 1     # strong vortex at the centre
+    i_weak = int(round((L / 2 + 5e4) / dx))
+    assert img[n // 2, i_weak] > 2.5e-3 and img[i_weak, n // 2] < 1e-4      # weak vortex: +x of the centre, not +y
+    v = np.fromfile(str(tmp_path / "output" / "v_step_0.bin"), dtype="<f4", count=n * n).reshape((n, n)).transpose()
+    j, r = n // 2, int(round(2e4 / dx))
+    assert v[j, n // 2 + r] > 5 and v[j, n // 2 - r] < -5                    # v = dpsi/dx: cyclonic flow, northward east of the core

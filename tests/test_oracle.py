@@ -315,3 +315,15 @@ def test_rk4_fourth_order_convergence():
     e1 = np.linalg.norm(run(60.0) - ref)
     e2 = np.linalg.norm(run(30.0) - ref)
     assert 10.0 < e1 / e2 < 24.0
+
+
+def test_oracle_under_asan_ubsan():
+    """make -C oracle asan: the oracle and its self-test (oracle/selftest.c) built with -fsanitize=address,undefined
+    (sanitizers run on the CPU side only; GPU ASan is unavailable on this pool)."""
+    import subprocess
+    d = os.path.join(os.path.dirname(HERE), "oracle")
+    subprocess.check_call(["make", "-s", "-C", d, "asan"])
+    res = subprocess.run([os.path.join(d, "_asan", "selftest")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         env=dict(os.environ, OMP_NUM_THREADS="2"))
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "selftest ok" in res.stdout and "ERROR: AddressSanitizer" not in res.stderr and "runtime error" not in res.stderr

@@ -40,6 +40,7 @@ extern "C" const char *fb_strerror(int s)
     }
 }
 extern "C" const char *fb_last_error(void) { return g_last_error.c_str(); }
+extern "C" void fb_internal_set_error(const char *msg) { g_last_error = msg ? msg : ""; }   // fb_fieldio.cpp, fb_slab_comm.cpp
 extern "C" int fb_version(void) { return 100; }
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
@@ -1198,27 +1199,4 @@ extern "C" int fb_model_get_diag(fb_model *m, float *d_psi, float *d_u, float *d
     return FB_OK;
 }
 
-// --------------------------------------------------------------------------------------------
-// field I/O (host): fieldio.cpp:7-33 -- same bytes on disk, same stderr lines, plus a status
-// --------------------------------------------------------------------------------------------
-extern "C" int fb_write_field(const char *filename, const float *data, size_t len)
-{
-    if (!filename || !data) return fail(FB_EINVAL, "fb_write_field: NULL");
-    FILE *f = fopen(filename, "wb");
-    if (!f) { perror("Write field."); return fail(FB_EIO, std::string("cannot open ") + filename); }
-    const size_t n = fwrite(data, sizeof(float), len, f);
-    fclose(f);
-    fprintf(stderr, "Output %s\n", filename);                 // fieldio.cpp:18
-    return n == len ? FB_OK : fail(FB_EIO, std::string("short write: ") + filename);
-}
-
-extern "C" int fb_read_field(const char *filename, float *data, size_t len)
-{
-    if (!filename || !data) return fail(FB_EINVAL, "fb_read_field: NULL");
-    FILE *f = fopen(filename, "rb");
-    if (!f) { perror("Read field."); return fail(FB_EIO, std::string("cannot open ") + filename); }
-    const size_t n = fread(data, sizeof(float), len, f);
-    fclose(f);
-    fprintf(stderr, "%d bytes read: %s\n", (int)n, filename);  // fieldio.cpp:32 (elements, labelled bytes)
-    return n == len ? FB_OK : fail(FB_EIO, std::string("short read: ") + filename);
-}
+// field I/O (fb_write_field / fb_read_field, writeField / readField): fb_fieldio.cpp

@@ -2,9 +2,12 @@
 //
 // `fftwf_operation<XPTS,YPTS>` keeps the reference's template signature and method names
 // (fftwfop.hpp:9-29) so that reference-shaped host code compiles unchanged; every method
-// forwards to include/fftbaro.h and works on DEVICE buffers.  The FFTW entry points the
-// drivers use (main.cpp:103-135,154) are provided as `fbw_*` functions with FFTW's argument
-// order; see INTEGRATION.md for the three-line diff a maintainer applies to main.cpp.
+// forwards to include/fftbaro.h.  Buffers are device memory (fb_malloc / fbw_malloc, asynchronous on the
+// context's stream) or the pinned host memory fftwf_malloc of include/fftw3_fb.h returns; with
+// -DFFTWFOP_HIP_SYNCHRONOUS every method returns only when its result is readable by the host, which is what
+// reference-shaped code that loops over the arrays between operator calls needs (fftw_shape_check.cpp).
+// The FFTW entry points the drivers use (main.cpp:103-135,154) exist twice: with FFTW's exact names and
+// signatures in include/fftw3_fb.h (lib/libfftw3f_fb.so), and as the asynchronous device-memory `fbw_*` forms below.
 #ifndef FFTWFOP_HIP_HPP
 #define FFTWFOP_HIP_HPP
 #include <cassert>
@@ -13,7 +16,9 @@
 
 #include "../../include/fftbaro.h"
 
+#ifndef FFTW3_FB_H
 typedef float fftwf_complex[2];                       // same layout as FFTW's (fftw3.h)
+#endif
 
 inline void fb_must(int status, const char *what)
 {
@@ -26,6 +31,11 @@ inline void fb_must(int status, const char *what)
 template <int XPTS, int YPTS> class fftwf_operation {
 private:
     fb_ctx *ctx;
+#ifdef FFTWFOP_HIP_SYNCHRONOUS
+    void done() { fb_must(fb_synchronize(ctx), "fftwf_operation"); }
+#else
+    void done() {}
+#endif
     const int HALF_XPTS = (int)(XPTS / 2) + 1, HALF_YPTS = (int)(YPTS / 2) + 1, HALF_GRIDS = XPTS * HALF_YPTS;
 public:
     fftwf_operation(float Lx, float Ly) : ctx(nullptr) { fb_must(fb_create(&ctx, XPTS, YPTS, Lx, Ly), "fftwf_operation"); }   // fftwfop.cpp:5-79
@@ -33,11 +43,11 @@ public:
     fftwf_operation(const fftwf_operation &) = delete;
     fftwf_operation &operator=(const fftwf_operation &) = delete;
 
-    void gradx(fftwf_complex *in, fftwf_complex *out) { fb_must(fb_gradx(ctx, (const float *)in, (float *)out), "gradx"); }                           // :87-94
-    void grady(fftwf_complex *in, fftwf_complex *out) { fb_must(fb_grady(ctx, (const float *)in, (float *)out), "grady"); }                           // :96-103
-    void laplacian(fftwf_complex *in, fftwf_complex *out) { fb_must(fb_laplacian(ctx, (const float *)in, (float *)out), "laplacian"); }               // :105-110
-    void invertLaplacian(fftwf_complex *in, fftwf_complex *out) { fb_must(fb_invert_laplacian(ctx, (const float *)in, (float *)out), "invertLaplacian"); }   // :112-117
-    void dealiase(fftwf_complex *in, fftwf_complex *out) { fb_must(fb_dealiase(ctx, (const float *)in, (float *)out), "dealiase"); }                  // :119-124
+    void gradx(fftwf_complex *in, fftwf_complex *out) { fb_must(fb_gradx(ctx, (const float *)in, (float *)out), "gradx"); done(); }                           // :87-94
+    void grady(fftwf_complex *in, fftwf_complex *out) { fb_must(fb_grady(ctx, (const float *)in, (float *)out), "grady"); done(); }                           // :96-103
+    void laplacian(fftwf_complex *in, fftwf_complex *out) { fb_must(fb_laplacian(ctx, (const float *)in, (float *)out), "laplacian"); done(); }               // :105-110
+    void invertLaplacian(fftwf_complex *in, fftwf_complex *out) { fb_must(fb_invert_laplacian(ctx, (const float *)in, (float *)out), "invertLaplacian"); done(); }   // :112-117
+    void dealiase(fftwf_complex *in, fftwf_complex *out) { fb_must(fb_dealiase(ctx, (const float *)in, (float *)out), "dealiase"); done(); }                  // :119-124
 
     inline int reflectedXWavenumberIndex(int i) { assert(i >= 1 && "Input of ReflectedXWavenumberIndex must >= 1"); return XPTS - i; }
     inline int HIDX(int i, int j) { return HALF_YPTS * i + j; }
