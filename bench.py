@@ -8,11 +8,19 @@ main.cpp:286-317) of the synthetic workload below, state resident in HBM.  Print
 
 Workload at N=1: BASELINE.json configs[2] -- 4096x4096 Kuo2004 initial field, fp32,
 dt = 3*1024/4096 s (the reference's dt=3 s is unstable above N~2300).
-For N>1 the same grid is split into x-row / ky-column slabs (strong scaling), see DESIGN.md.
+For N>1 the same grid is split into x-row / ky-column slabs (strong scaling; the engine drives the
+RCCL all-to-all transposes itself, csrc/fb_slab_driver.h), see DESIGN.md section 6.
+
+Roofline conventions: `roofline.achieved` uses the contract's algorithmic bytes (SURVEY.md
+8(d): 8 N^2 per 1-D pass over a field, 320 N^2 per step); next to it the line carries the bytes the kernels really
+move (`traffic`, from the committed rocprofv3 PMC passes), `traffic_frac` = those bytes / launch time / peak, and at
+step level `tight_frac` against the fully fused lower bound of 256 N^2.
 """
 import argparse
+import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -26,44 +34,77 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 # credited half).  Sum over the four kernels of a stage = 80 N^2; x 4 stages = 320 N^2 per step.
 ALG_N2 = {"k_col_strided_bwd4": 16.0, "k_row_fused": 40.0, "k_col_strided_fwd1": 4.0, "k_col_mid": 20.0,
           "k_col_full": 40.0}      # the single-pass x transform does the work of the three column kernels
-# HBM bytes per launch from the PMC passes committed in profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-# separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only known for the 4096^2 run
-PMC_KERNEL = {"k_col_strided_bwd4": "k_col_strided<64, 1>", "k_row_fused": "k_row8<false>",
-              "k_col_strided_fwd1": "k_col_strided<64, -1>", "k_col_mid": "k_col_mid<64>", "k_col_full": "k_col_full"}
+# kernel-name prefixes of the classes in the rocprofv3 output (profiles/*_pmc_traffic_<n>.json)
+PMC_PREFIX = {"k_col_strided_bwd4": ("k_col_strided<", ", 1>"), "k_row_fused": ("k_row", ""), "k_col_strided_fwd1": ("k_col_strided<", ", -1>"),
+              "k_col_mid": ("k_col_mid<", ""), "k_col_full": ("k_col_full", "")}
 
 
-def pmc_traffic(kernel, n):
-    path = os.path.join(ROOT, "profiles", "r01_i_pmc_traffic_4096.json")
-    if n != 4096 or not os.path.exists(path):
-        return None
+def pmc_profile(n):
+    """The newest committed PMC summary for this grid: (path relative to the repo, parsed json) or (None, None)."""
+    best = None
+    for p in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%d.json" % n)):
+        m = re.match(r"r(\d+)_([a-z]+)_pmc", os.path.basename(p))
+        if m:
+            key = (int(m.group(1)), len(m.group(2)), m.group(2))
+            if best is None or key > best[0]:
+                best = (key, p)
+    if best is None:
+        return None, None
     try:
-        ks = json.load(open(path))["kernels"]
-        if kernel == "k_col_full":                  # four template instances (one per RK stage): average them
-            v = [d["hbm_bytes_per_launch_corrected"] for k, d in ks.items() if k.startswith("k_col_full")]
-            return sum(v) / len(v) if v else None
-        return ks[PMC_KERNEL[kernel]]["hbm_bytes_per_launch_corrected"]
-    except (KeyError, ValueError):
+        return os.path.relpath(best[1], ROOT), json.load(open(best[1]))
+    except ValueError:
+        return None, None
+
+
+def pmc_traffic(prof, kernel, launches_per_step=4):
+    """HBM-side bytes per launch of a kernel class (average over its template instances, weighted by launches)."""
+    if not prof:
         return None
+    pre, suf = PMC_PREFIX[kernel]
+    tot = cnt = 0.0
+    for k, d in prof.get("kernels", {}).items():
+        if k.startswith(pre) and k.endswith(suf) if suf else k.startswith(pre):
+            if kernel == "k_row_fused" and d.get("launches", 0) < 8:          # set_vort / get_vort launches of the non-fused modes
+                continue
+            tot += d["hbm_bytes_per_launch_corrected"] * d["launches"]
+            cnt += d["launches"]
+    return tot / cnt if cnt else None
 
 
-def cpu_baseline(n, dt, kind, steps):
-    """Oracle ("port") timed on ONE host core -- the reference is single-threaded."""
+def cpu_leg(n, dt, kind, steps, threads):
     import ctypes
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     try:
-        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(threads)
     except OSError:
-        pass
+        threads = 1
     m = O.Model(n, n, dt=dt)
     m.set_vort(O.make_field(kind, n))
     m.step(1)
     t0 = time.perf_counter()
     m.step(steps)
-    el = time.perf_counter() - t0
-    return {"value": steps / el, "unit": "steps/s", "cores": 1, "kind": "port",
+    return steps / (time.perf_counter() - t0), threads
+
+
+def cpu_baseline(n, dt, kind, steps):
+    """The oracle ("port": the reference's unfused loop structure with its own FFT) on the GPU box's host cores: ONE core is
+    the faithful figure -- the reference is single-threaded (Makefile:2, no threads anywhere) -- plus the same code on all
+    cores (OpenMP) and the small configs, as SURVEY.md 8(d) asks.  Bounded: about 20-30 s in all."""
+    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    v1, _ = cpu_leg(n, dt, kind, steps, 1)
+    vall, used = cpu_leg(n, dt, kind, max(steps, 5), nproc)
+    small = {}
+    for ns, ks in ((256, 40), (1024, 10)):
+        if ns < n:
+            v, _ = cpu_leg(ns, 3.0, "elliptic", ks, 1)
+            small["%dx%d elliptic, 1 core" % (ns, ns)] = v
+    return {"value": v1, "unit": "steps/s", "cores": 1, "kind": "port",
             "sample": "%dx%d %s, %d RK4 steps after 1 warm-up, oracle/liboracle.so (own FFT, reference loop structure), 1 thread"
-                      % (n, n, kind, steps)}
+                      % (n, n, kind, steps),
+            "all_cores": {"value": vall, "unit": "steps/s", "cores": used, "nproc": nproc,
+                          "sample": "same workload, %d steps, OpenMP over the oracle's loops and FFT batches" % max(steps, 5)},
+            "other_configs_steps_per_s": small}
 
 
 def main():
@@ -73,7 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--grid", "--n", dest="n", type=int, default=4096, help="grid points per side")
     ap.add_argument("--kind", default=None, help="initial field (default: kuo2004 for n>=4096 else elliptic)")
-    ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="oracle steps for the 1-core cpu_baseline leg (0 = skip cpu_baseline)")
     ap.add_argument("--spinup-steps", type=int, default=None,
                     help="untimed device spin-up before the warm-up: this many steps, then the state is reset (default: ~30 ms worth; 0 = none)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
@@ -94,6 +135,7 @@ def main():
     kind = args.kind or ("kuo2004" if n >= 4096 else "elliptic")
     dt = 3.0 if n <= 1024 else 3.0 * 1024 / n
     K, W = args.steps, args.warmup
+    slab_info = None
 
     if world > 1:
         import torch.distributed as dist
@@ -103,8 +145,12 @@ def main():
             dist.init_process_group(args.backend)
         from importlib import import_module
         slab = import_module("xlab-fftbarotropic_amd.slab")
+        # the engine-driven model: local passes, exchange buffers and the RCCL all-to-all transposes behind the C ABI
         model = slab.SlabModel(n, n, dt=dt, rank=rank, world=world)
-        v0_local = slab.local_rows(X.make_field(kind, n), rank, world)
+        slab_info = {"rows_per_rank": model.XL, "active_cols_per_rank": model.KA, "frozen_cols_per_rank": model.KF,
+                     "field_groups": model.field_groups, "row_chunks": model.row_chunks,
+                     "transport": "rccl" if args.backend == "nccl" else "gloo callback (rehearsal)"}
+        v0_local = torch.from_numpy(slab.local_rows(X.make_field(kind, n), rank, world)).cuda()
 
         def reset_state():
             model.set_vort_local(v0_local)
@@ -143,7 +189,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -158,7 +204,10 @@ def main():
                                % (n, n, kind, dt), "grid": [n, n], "parallelism": "slab%d" % world if world > 1 else "single"},
         "achieved_hbm_GBs": alg_bytes * steps_per_s / 1e9,
         "step_roofline_frac": alg_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBS * world),
+        "tight_frac": 256.0 * n * n * steps_per_s / 1e9 / (HBM_PEAK_GBS * world),
     }
+    if slab_info:
+        out["config"]["slab"] = slab_info
 
     if rank == 0 and world == 1:
         # per-kernel HIP-event timing over a second pass of the same K steps (events on the launch stream)
@@ -169,18 +218,32 @@ def main():
         per = {k: (ms / max(cnt, 1)) for k, (ms, cnt) in prof.items()}
         tot = {k: ms for k, (ms, cnt) in prof.items()}
         dom = max(tot, key=tot.get)
+        pmc_path, pmc = pmc_profile(n)
+        traffic = {k: pmc_traffic(pmc, k) for k in per}
         ach = ALG_N2[dom] * n * n / (per[dom] * 1e-3) / 1e9
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, n),
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic[dom],
+                           "traffic_frac": (traffic[dom] / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic[dom] else None,
+                           # provenance of `traffic`: NOT measured by this run (PMC passes need their own rocprofv3 runs)
+                           "traffic_source": ({"file": pmc_path, "commit": pmc.get("commit"), "command": pmc.get("command")} if pmc else None),
                            "avg_launch_ms": per[dom], "alg_bytes_per_launch": ALG_N2[dom] * n * n}
         out["kernels_ms_per_launch"] = per
         out["kernels_ms_per_step"] = {k: v / K for k, v in tot.items()}
+        # credit-based and counter-based rates side by side: the contract's 8 N^2-per-pass credit counts the row pass's
+        # traffic twice (it reads 4 C and writes 1 C for 40 N^2 of credit), the counter bytes are what really crosses the fabric
+        out["kernels_GBs"] = {k: {"credit": ALG_N2[k] * n * n / (per[k] * 1e-3) / 1e9,
+                                  "traffic": (traffic[k] / (per[k] * 1e-3) / 1e9) if traffic[k] else None} for k in per}
+        if all(traffic.values()):
+            per_step = sum(traffic[k] * (prof[k][1] / K) for k in per)
+            out["traffic_bytes_per_step"] = per_step
+            out["traffic_frac"] = per_step * steps_per_s / 1e9 / HBM_PEAK_GBS
         if args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(n, dt, kind, args.cpu_steps)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
+        model.close()
         dist.destroy_process_group()
 
 

@@ -159,35 +159,56 @@ int fb_model_time_steps(fb_model *m, int nsteps, float *total_ms);
 int fb_model_profile_steps(fb_model *m, int nsteps, float *ms_sum, int *launches);
 
 /* ---------------------------------------------------------------------------------------
- * Slab decomposition over the GPUs of one node (one process per GPU).
- * No reference counterpart -- the reference is single-process.  Process `rank` of `world`
- * (a power of two) owns the x rows [rank*XL, (rank+1)*XL), XL = nx/world, of every physical
- * field and the ky columns [ky0, ky0+KS) of every spectral field (KS = 16*ceil((ny/2+1)/(16*world))).
- * The engine does the local passes; the CALLER does the two all-to-all transposes per RK stage
- * (RCCL via torch.distributed, or ncclSend/ncclRecv) on four buffers it owns, E = nx*KS complex:
- *   w4_send [world][4][XL][KS]   destination-blocked: block d = rows d*XL..(d+1)*XL of the four fields,
- *                                 written by FB_PH_PRIME / FB_PH_COL_FWD, finished by FB_PH_COL_BWD
- *   w4_recv [world][4][XL][KS]   block s comes from rank s (its ky slab of this rank's rows)
- *   t_send  [world][XL][KS]      written by FB_PH_ROW / FB_PH_R2C_ROWS; block d goes to rank d
- *   t_recv  [nx][KS]             block s (rows s*XL..) comes from rank s
- * so each transpose is ONE equal-split all-to-all of a contiguous buffer (4E and E complex).
- * One RK4 step = for stage in 0..3 { COL_BWD; all-to-all(w4); ROW; all-to-all(t); COL_FWD(stage) },
- * preceded once by PRIME after the state was set.  The record path (C2R_*) runs the transposes in
- * the opposite roles: C2R_COLS leaves [dst][XL][KS] in t_recv, all-to-all(t_recv -> t_send), C2R_ROWS.
+ * Multi-GPU: slab decomposition over the GPUs of one node, one process per GPU, RCCL all-to-all transposes over
+ * xGMI between the row and the column passes.  No reference counterpart -- the reference is
+ * single-process; one fb_slab_step() computes what one iteration of main.cpp:259-323 computes, on this rank's share.
+ *
+ * Rank r of `world` (a power of two) owns the x rows [r*XL, (r+1)*XL), XL = nx/world, of every physical field, and of
+ * every spectral field KA "active" ky columns [r*KA, (r+1)*KA) -- the columns below world*KA hold every mode inside
+ * the dealiasing circle and are exchanged twice per RK stage -- plus KF "frozen" columns [world*KA + r*KF, ...): their
+ * modes are masked (fftwfop.cpp:57-61), never change (SURVEY.md note N1), and cross the links once per fb_slab_set_vort_local.
+ * The engine owns the exchange buffers, two HIP streams (compute / communication) and the schedule: per stage the four
+ * derivative fields leave field group by field group behind their backward x sub-pass, the tendency leaves row chunk
+ * by row chunk behind the row pass (fb_slab_plan reports the granularity, which follows the message size).
+ *
+ * Transports: fb_slab_connect_rccl (the product: grouped ncclSend/ncclRecv; rank 0 obtains the id from
+ * fb_slab_unique_id and hands it to the other ranks -- file, environment, torch.distributed, MPI ...),
+ * fb_slab_connect_local (all ranks as threads of ONE process on ONE GPU: rehearsal of the schedule),
+ * fb_slab_connect_callback (the caller moves the bytes).  world == 1 needs no transport.
  * ------------------------------------------------------------------------------------- */
+typedef struct fb_slab fb_slab;
+#define FB_UNIQUE_ID_BYTES 128
+int fb_slab_unique_id(char *id128);                       /* ncclGetUniqueId */
+int fb_slab_create(fb_slab **out, int nx, int ny, float lx, float ly, float nu, float dt, int rank, int world);
+int fb_slab_destroy(fb_slab *s);
+int fb_slab_connect_rccl(fb_slab *s, const char *id128);  /* ncclCommInitRank: collective over all ranks */
+int fb_local_hub_create(void **hub, int world);
+int fb_local_hub_destroy(void *hub);
+int fb_slab_connect_local(fb_slab *s, void *hub);
+/* For every peer p: `count` floats at send + p*stride + offset go to recv + rank*stride + offset of peer p (own block
+ * included); must be complete, or ordered on hip_stream, when the callback returns.  Return 0 on success. */
+typedef int (*fb_alltoall_fn)(void *user, const float *d_send, float *d_recv, size_t stride, size_t offset, size_t count, void *hip_stream);
+int fb_slab_connect_callback(fb_slab *s, fb_alltoall_fn fn, void *user);
+/* this rank's rows [XL][ny] (device pointers): readField + r2c (main.cpp:143-144,256), vort_src (main-shallow-water.cpp:304;
+ * NULL = zeros), the record path (main.cpp:273-281) */
+int fb_slab_set_vort_local(fb_slab *s, const float *d_rows);
+int fb_slab_set_source_local(fb_slab *s, const float *d_rows);
+int fb_slab_get_vort_local(fb_slab *s, float *d_rows);
+int fb_slab_step(fb_slab *s, int nsteps);
+int fb_slab_synchronize(fb_slab *s);
+int fb_slab_time_steps(fb_slab *s, int nsteps, float *total_ms);
+/* exchanges a known pattern of world*count floats through the connected transport; *wrong_words = 0 when every word arrived */
+int fb_slab_transport_selftest(fb_slab *s, size_t count, size_t *wrong_words);
+int fb_slab_info(fb_slab *s, int *rows_local, int *cols_active, int *cols_frozen, int *ky0_active, int *ky0_frozen,
+                 int *field_groups, int *row_chunks);
+/* host logic, no GPU needed: XL, KA, KF of a decomposition */
+int fb_slab_geometry(int nx, int ny, int world, int *rows_local, int *cols_active, int *cols_frozen);
+/* host logic, no GPU needed: the operations of ONE RK stage in issue order, ops[i] = 16*kind + argument, kind =
+ * 1 backward x sub-pass of field group g, 2 all-to-all of field group g, 3 row pass of row chunk h, 4 all-to-all of
+ * tendency chunk h, 5 forward x pass + RK update.  Returns the number of operations (negative never; 0 on error). */
+int fb_slab_plan(int nx, int ny, int world, int *field_groups, int *row_chunks, int *ops, int cap);
+/* lower level: a context bound to one rank's slabs (the operator / FFT entry points above need world == 1) */
 int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, int rank, int world);
-int fb_slab_geometry(fb_ctx *ctx, int *rows_local, int *cols_per_slab, int *ky0, size_t *elems_per_field);
-int fb_model_create_slab(fb_model **out, fb_ctx *ctx, float nu, float dt, float *d_w4_send, float *d_w4_recv,
-                         float *d_t_send, float *d_t_recv);
-#define FB_PH_PRIME     0   /* derivatives of the current vort_c -> w4_send                               */
-#define FB_PH_COL_BWD   1   /* backward x sub-pass on w4_send (then transpose w4_send -> w4_recv)          */
-#define FB_PH_ROW       2   /* w4_recv -> c2r rows, Jacobian (+ local rows of vort_src), r2c rows -> t_send */
-#define FB_PH_COL_FWD   3   /* t_recv -> forward x pass, viscosity, mask, RK stage `stage`, derivatives    */
-#define FB_PH_R2C_ROWS  4   /* d_real_in (local rows [XL][ny]) -> t_send           (set_vort, first half)  */
-#define FB_PH_R2C_COLS  5   /* t_recv -> vort_c                                    (set_vort, second half) */
-#define FB_PH_C2R_COLS  6   /* copy of vort_c -> x-backward-transformed columns in t_recv (get_vort, 1st half) */
-#define FB_PH_C2R_ROWS  7   /* t_send ([src][XL][KS]) -> d_real_out (local rows, normalised)                  */
-int fb_model_phase(fb_model *m, int phase, int stage, const float *d_real_in, float *d_real_out);
 
 /* ---------------------------------------------------------------------------------------
  * Field I/O on HOST buffers.  Replaces writeField / readField (fieldio.hpp:5-6,

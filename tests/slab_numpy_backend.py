@@ -1,12 +1,17 @@
 """CPU test double of the slab compute backend (fp64 numpy), for exercising the exchange logic of
 xlab-fftbarotropic_amd/slab.py under gloo.  TEST INFRASTRUCTURE: not part of the product.
-Buffer layouts are the contract of include/fftbaro.h ("Slab decomposition")."""
+
+Buffer layouts are the engine's (include/fftbaro.h "Multi-GPU", csrc/fftbaro.hip GroupBufs), per column group g
+(0 = this rank's slab of the ACTIVE ky columns, 1 = its slab of the FROZEN ones):
+    w4_send[g] [dst][4][XL][ncols_g]    w4_recv[g] [src][4][XL][ncols_g]
+    t_send[g]  [dst][XL][ncols_g]       t_recv[g]  [nx][ncols_g]
+The double is deliberately lazy the way the engine is: a field only reaches w4_send when col_bwd() is asked for it and a
+tendency row only reaches t_send when row() is asked for it, so a schedule that forgets a field group or a row chunk
+produces wrong numbers instead of passing by accident."""
 import numpy as np
 import torch
 
 import ref_numpy as R
-
-PH_PRIME, PH_COL_BWD, PH_ROW, PH_COL_FWD, PH_R2C_ROWS, PH_R2C_COLS, PH_C2R_COLS, PH_C2R_ROWS = range(8)
 
 
 class NumpyBackend:
@@ -14,100 +19,127 @@ class NumpyBackend:
         from importlib import import_module
         slab = import_module("xlab-fftbarotropic_amd.slab")
         self.nx, self.ny, self.hy, self.rank, self.world = nx, ny, ny // 2 + 1, rank, world
-        self.XL, self.KS = slab.slab_geometry(nx, ny, world)
-        self.E = nx * self.KS
-        self.ky0 = rank * self.KS
+        self.XL, self.KA, self.KF = slab.slab_geometry(nx, ny, world)
+        self.ncols = [self.KA, self.KF]
+        self.katot = world * self.KA
+        self.ktot = self.katot + world * self.KF                        # >= hy: columns beyond hy are padding
+        self.ky = [np.arange(rank * self.KA, (rank + 1) * self.KA), self.katot + np.arange(rank * self.KF, (rank + 1) * self.KF)]
         gx, gy, lap, lapi, mask = R.tables(nx, ny, Lx, Ly)
-        ptot = self.KS * world
-        pad = lambda a: np.concatenate([a, np.zeros((nx, ptot - self.hy))], axis=1)[:, self.ky0:self.ky0 + self.KS]
+        padc = lambda a, fill: np.concatenate([a.astype(np.float64), np.full((nx, self.ktot - self.hy), fill)], axis=1)
         self.ikx = 1j * gx.astype(np.float64)[:, None]
-        gyp = np.concatenate([gy.astype(np.float64), np.zeros(ptot - self.hy)])
-        self.iky = 1j * gyp[None, self.ky0:self.ky0 + self.KS]
-        self.lap = pad(lap.astype(np.float64))
-        lapi_p = np.concatenate([lapi.astype(np.float64), np.ones((nx, ptot - self.hy))], axis=1)
-        self.lapi = lapi_p[:, self.ky0:self.ky0 + self.KS]
-        self.mask = pad(mask.astype(np.float64))
+        gyp = np.concatenate([gy.astype(np.float64), np.zeros(self.ktot - self.hy)])
+        lap_p, lapi_p, mask_p = padc(lap, 0.0), padc(lapi, 1.0), padc(mask, 0.0)
+        self.iky = [1j * gyp[None, k] for k in self.ky]
+        self.lap = [lap_p[:, k] for k in self.ky]
+        self.lapi = [lapi_p[:, k] for k in self.ky]
+        self.mask = [mask_p[:, k] for k in self.ky]
+        assert not self.mask[1].any(), "the frozen slab must hold masked modes only"
         self.nu, self.dt = float(np.float32(nu)), float(np.float32(dt))
         z = lambda n: torch.zeros(n, dtype=torch.complex128)
-        self.w4_send, self.w4_recv, self.t_send, self.t_recv = z(4 * self.E), z(4 * self.E), z(self.E), z(self.E)
+        self.w4_send = [z(4 * nx * n) for n in self.ncols]
+        self.t_send = [z(nx * n) for n in self.ncols]
         if world == 1:
-            self.w4_recv = self.w4_send
-            self.t_recv = self.t_send
-        self.Z = np.zeros((nx, self.KS), dtype=np.complex128)
+            self.w4_recv, self.t_recv = self.w4_send, self.t_send
+        else:
+            self.w4_recv = [z(4 * nx * n) for n in self.ncols]
+            self.t_recv = [z(nx * n) for n in self.ncols]
+        self.Z = [np.zeros((nx, n), dtype=np.complex128) for n in self.ncols]       # vort_c, [kx][local ky]
         self.Z0 = self.Zc = self.acc = None
+        self.pending = None                                                           # group 0: x-transformed derivative fields not yet in w4_send
         self.src = np.zeros((self.XL, ny))
 
     # helpers ------------------------------------------------------------------------------
-    def _derive(self, z):
-        psi = z / self.lapi
-        d = np.stack([self.ikx * z, self.iky * z, self.iky * psi, self.ikx * psi])     # main.cpp:151,165,198,212
-        return d
+    def _derive(self, z, g):
+        psi = z / self.lapi[g]
+        return np.stack([self.ikx * z, self.iky[g] * z, self.iky[g] * psi, self.ikx * psi])     # main.cpp:151,165,198,212
 
-    def _rows_from_w4(self, f):
-        blk = self.w4_recv.numpy().reshape(self.world, 4, self.XL, self.KS)[:, f]       # [src][XL][KS]
-        return np.concatenate(list(blk), axis=1)[:, :self.hy]                            # [XL][hy]
+    def _blocked(self, fields_x, g):
+        """[4][x][ncols] -> flat [dst][4][XL][ncols]"""
+        n = self.ncols[g]
+        return np.ascontiguousarray(fields_x.reshape(4, self.world, self.XL, n).transpose(1, 0, 2, 3)).reshape(-1)
 
-    def _rows_from_t_send(self):
-        blk = self.t_send.numpy().reshape(self.world, self.XL, self.KS)
-        return np.concatenate(list(blk), axis=1)[:, :self.hy]
+    def _rows(self, bufs, nfields, f):
+        """field f of the row-side buffers of both groups -> [XL][hy]"""
+        parts = []
+        for g in (0, 1):
+            if self.ncols[g]:
+                blk = bufs[g].numpy().reshape(self.world, nfields, self.XL, self.ncols[g])[:, f]       # [src][XL][ncols]
+                parts.append(np.concatenate(list(blk), axis=1))
+        return np.concatenate(parts, axis=1)[:, :self.hy]
 
-    def _rows_to_t(self, rows_spec):
-        ptot = self.KS * self.world
-        full = np.concatenate([rows_spec, np.zeros((self.XL, ptot - self.hy), dtype=np.complex128)], axis=1)
-        blk = np.stack([full[:, d * self.KS:(d + 1) * self.KS] for d in range(self.world)])
-        self.t_send.view(-1)[:] = torch.from_numpy(np.ascontiguousarray(blk).reshape(-1))
+    def _rows_to_t(self, rows_spec, x0, frozen):
+        """half-spectrum rows [nrows][hy] of local rows x0.. -> t_send, blocked by destination rank"""
+        nrows = rows_spec.shape[0]
+        full = np.concatenate([rows_spec, np.zeros((nrows, self.ktot - self.hy), dtype=np.complex128)], axis=1)
+        for g in ((0, 1) if frozen else (0,)):
+            n = self.ncols[g]
+            if not n:
+                continue
+            base = 0 if g == 0 else self.katot
+            view = self.t_send[g].numpy().reshape(self.world, self.XL, n)
+            for d in range(self.world):
+                view[d, x0:x0 + nrows] = full[:, base + d * n:base + (d + 1) * n]
 
-    # phases -------------------------------------------------------------------------------
-    def phase(self, ph, stage=0, real_in=None, real_out=None):
-        nx, ny = self.nx, self.ny
-        if ph == PH_PRIME:
-            self.pending = self._derive(self.Z)
-            self._stash_block()
-        elif ph == PH_COL_BWD:
-            pass                                         # the test double does the whole x pass in _stash_block
-        elif ph == PH_ROW:
-            c2r = lambda f: np.fft.irfft(self._rows_from_w4(f), n=ny, axis=1) * ny / (nx * ny)
-            dzdx, dzdy, u, v = c2r(0), c2r(1), -c2r(2), c2r(3)
-            t = -u * dzdx - v * dzdy + self.src                                          # main.cpp:225-227
-            self._rows_to_t(np.fft.rfft(t, axis=1))
-        elif ph == PH_COL_FWD:
-            That = np.fft.fft(self.t_recv.numpy().reshape(nx, self.KS), axis=0)
-            if stage == 0:
-                self.Z0, self.Zc = self.Z, self.Z
-            k = (That + self.Zc * self.lap * self.nu) * self.mask                        # main.cpp:148,240-243,296
-            dt = self.dt
-            if stage == 0:
-                self.acc = k; self.Zc = self.Z0 + k * (dt / 2)
-            elif stage == 1:
-                self.acc = self.acc + 2 * k; self.Zc = self.Z0 + k * (dt / 2)
-            elif stage == 2:
-                self.acc = self.acc + 2 * k; self.Zc = self.Z0 + k * dt
+    # phases (names follow csrc/fb_slab_driver.h) -------------------------------------------
+    def prime(self):
+        for g in (0, 1):
+            if not self.ncols[g]:
+                continue
+            cols = np.fft.ifft(self._derive(self.Z[g], g), axis=1) * self.nx                       # [4][x][ncols]
+            if g == 0:
+                self.pending = cols
+                self.w4_send[0].zero_()
             else:
-                self.Z = self.Z0 + (self.acc + k) * dt / 6; self.Zc = self.Z
-            self.pending = self._derive(self.Zc)
-            self._stash_block()
-        elif ph == PH_R2C_ROWS:
-            self._rows_to_t(np.fft.rfft(real_in.numpy().astype(np.float64), axis=1))
-        elif ph == PH_R2C_COLS:
-            self.Z = np.fft.fft(self.t_recv.numpy().reshape(nx, self.KS), axis=0)
-        elif ph == PH_C2R_COLS:
-            cols = np.fft.ifft(self.Z, axis=0) * nx                                      # [x][KS] == [dst][XL][KS]
-            self.t_recv.view(-1)[:] = torch.from_numpy(np.ascontiguousarray(cols).reshape(-1))
-        elif ph == PH_C2R_ROWS:
-            real_out.copy_(torch.from_numpy(np.fft.irfft(self._rows_from_t_send(), n=ny, axis=1) * ny / (nx * ny)))
+                self.w4_send[1].numpy()[:] = self._blocked(cols, 1)                                # frozen columns: final, sent once
+
+    def col_bwd(self, f0, f1):
+        view = self.w4_send[0].numpy().reshape(self.world, 4, self.XL, self.KA)
+        view[:, f0:f1] = self.pending[f0:f1].reshape(f1 - f0, self.world, self.XL, self.KA).transpose(1, 0, 2, 3)
+
+    def row(self, x0, nrows):
+        nx, ny = self.nx, self.ny
+        c2r = lambda f: np.fft.irfft(self._rows(self.w4_recv, 4, f)[x0:x0 + nrows], n=ny, axis=1) * ny / (nx * ny)
+        dzdx, dzdy, u, v = c2r(0), c2r(1), -c2r(2), c2r(3)
+        t = -u * dzdx - v * dzdy + self.src[x0:x0 + nrows]                                        # main.cpp:225-227
+        self._rows_to_t(np.fft.rfft(t, axis=1), x0, frozen=False)
+
+    def col_fwd(self, stage):
+        nx = self.nx
+        That = np.fft.fft(self.t_recv[0].numpy().reshape(nx, self.KA), axis=0)
+        if stage == 0:
+            self.Z0, self.Zc = self.Z[0], self.Z[0]
+        k = (That + self.Zc * self.lap[0] * self.nu) * self.mask[0]                              # main.cpp:148,240-243,296
+        dt = self.dt
+        if stage == 0:
+            self.acc = k; self.Zc = self.Z0 + k * (dt / 2)
+        elif stage == 1:
+            self.acc = self.acc + 2 * k; self.Zc = self.Z0 + k * (dt / 2)
+        elif stage == 2:
+            self.acc = self.acc + 2 * k; self.Zc = self.Z0 + k * dt
         else:
-            raise ValueError(ph)
+            self.Z[0] = self.Z0 + (self.acc + k) * dt / 6; self.Zc = self.Z[0]
+        self.pending = np.fft.ifft(self._derive(self.Zc, 0), axis=1) * nx
+        self.t_recv[0].zero_()                                                                   # consumed: a stale re-read would show
+        if self.world > 1:
+            self.w4_send[0].zero_()
 
-    def _stash_block(self):
-        cols = np.fft.ifft(self.pending, axis=1) * self.nx                               # [4][x][KS]
-        blocked = cols.reshape(4, self.world, self.XL, self.KS).transpose(1, 0, 2, 3)    # [dst][4][XL][KS]
-        self.w4_send.view(-1)[:] = torch.from_numpy(np.ascontiguousarray(blocked).reshape(-1))
+    def r2c_rows(self, real_rows):
+        self._rows_to_t(np.fft.rfft(np.asarray(real_rows, dtype=np.float64), axis=1), 0, frozen=True)
 
-    def to_device_real(self, a):
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+    def r2c_cols(self):
+        for g in (0, 1):
+            if self.ncols[g]:
+                self.Z[g] = np.fft.fft(self.t_recv[g].numpy().reshape(self.nx, self.ncols[g]), axis=0)
 
-    def empty_real(self):
-        return torch.empty((self.XL, self.ny), dtype=torch.float64)
+    def c2r_cols(self):
+        for g in (0, 1):
+            if self.ncols[g]:
+                cols = np.fft.ifft(self.Z[g], axis=0) * self.nx                                   # [x][ncols] == [dst][XL][ncols]
+                self.t_recv[g].numpy()[:] = np.ascontiguousarray(cols).reshape(-1)
+
+    def c2r_rows(self):
+        rows = self._rows(self.t_send, 1, 0)
+        return torch.from_numpy(np.fft.irfft(rows, n=self.ny, axis=1) * self.ny / (self.nx * self.ny))
 
     def set_source(self, src_local):
         self.src = np.zeros((self.XL, self.ny)) if src_local is None else np.asarray(src_local, dtype=np.float64)

@@ -425,10 +425,15 @@ def test_api_edge_cases(X, torch):
     m.set_source(z)
     m.step(1)
     assert float(m.vort().abs().max()) == 0.0
-    assert L_.fb_model_phase(m._h, 1, 0, None, None) == 1     # FB_PH_COL_BWD without a PRIME/COL_FWD before it
-    assert L_.fb_model_phase(m._h, 99, 0, None, None) == 1
-    assert L_.fb_model_phase(m._h, 4, 0, None, None) == 1     # R2C_ROWS without input
     h = C.c_void_p()
+    assert L_.fb_slab_create(C.byref(h), 256, 256, 6e5, 6e5, 6.5, 3.0, 0, 2) == 0          # a 2-rank model that was never connected ...
+    z2 = torch.zeros((128, 256), dtype=torch.float32, device="cuda")
+    assert L_.fb_slab_step(h, 1) == 1 and b"not connected" in L_.fb_last_error()                      # ... refuses to run
+    assert L_.fb_slab_set_vort_local(h, C.c_void_p(z2.data_ptr())) == 1
+    assert L_.fb_slab_connect_rccl(h, None) == 1
+    assert L_.fb_slab_destroy(h) == 0
+    assert L_.fb_model_create(C.byref(h), None, 6.5, 3.0) == 1
+    assert L_.fb_slab_create(C.byref(h), 256, 256, 6e5, 6e5, 6.5, 3.0, 0, 256) == 1        # nx / world < 2
     assert L_.fb_create_slab(C.byref(h), 256, 256, 6e5, 6e5, 3, 2) == 1   # rank out of range
     assert L_.fb_create_slab(C.byref(h), 256, 256, 6e5, 6e5, 0, 3) == 1   # world not a power of two
     assert L_.fb_create(C.byref(h), 32, 32, 6e5, 6e5) == 5                # below the minimum size

@@ -1,103 +1,252 @@
-"""GPU test of the slab-decomposed kernels: all `world` ranks' local passes run on the ONE GPU of
-the box, the all-to-all transposes are emulated by device copies with the same block semantics
-RCCL's all_to_all_single has.  Checks the SLAB addressing of the row kernel, the ky0 offsets of
-the column kernels and the phase order against the fused single-GPU path (bit for bit)."""
+"""GPU tests of the engine-driven multi-GPU step (fb_slab_*, csrc/fb_slab_driver.h) on the ONE GPU of the box.
+
+All `world` ranks live in this process, one host thread each, on the same device; the all-to-all transposes go through the
+in-process transport (fb_slab_connect_local: device-to-device copies ordered by the same kind of events the RCCL path
+relies on), so what runs is the real schedule -- two streams per rank, field groups and row chunks pipelined, frozen
+columns exchanged once -- with ranks racing each other.  The slab path must reproduce the fused single-GPU path bit for
+bit wherever both use the same kernels.  BASELINE configs 4 and 5 run here at FULL size.
+RCCL itself needs one GPU per rank; its call path is exercised with world = 1 (own block routed through ncclSend/ncclRecv)."""
+import os
+import threading
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-
-def _emulated_all_to_all(recv_list, send_list, world, n_per_block, offset=0):
-    for d in range(world):
-        for s in range(world):
-            recv_list[d][offset + s * n_per_block: offset + (s + 1) * n_per_block].copy_(
-                send_list[s][offset + d * n_per_block: offset + (d + 1) * n_per_block])
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 
 
-class _Group:
-    def __init__(self, X, slab, n, world, dt, src=None):
-        self.world, self.slab = world, slab
-        self.be = [slab.HipBackend(n, n, 6e5, 6e5, 6.5, dt, r, world) for r in range(world)]
-        self.E = self.be[0].FL              # tensor elements per field (float32 view)
-        self.blk = self.E // world
-
-    def xw4(self):
-        if self.world == 1:
-            return
-        _emulated_all_to_all([b.w4_recv for b in self.be], [b.w4_send for b in self.be], self.world, 4 * self.blk)
-
-    def xt(self, reverse=False):
-        if self.world == 1:
-            return
-        if reverse:
-            _emulated_all_to_all([b.t_send for b in self.be], [b.t_recv for b in self.be], self.world, self.blk)
-        else:
-            _emulated_all_to_all([b.t_recv for b in self.be], [b.t_send for b in self.be], self.world, self.blk)
-
-    def ph(self, ph, **kw):
-        for b in self.be:
-            b.phase(ph, **kw)
-
-
-@pytest.mark.parametrize("world,n,steps", [(1, 256, 3), (2, 256, 3), (4, 256, 2), (8, 512, 1), (2, 1024, 2), (4, 768, 2)])
-def test_slab_phases_match_fused_path(world, n, steps):
-    import torch
+def _slab():
     from importlib import import_module
+    return import_module("xlab-fftbarotropic_amd.slab")
+
+
+def run_ranks(world, fn):
+    """fn(rank) on `world` threads; re-raises the first failure."""
+    errs, out = [None] * world, [None] * world
+
+    def work(r):
+        try:
+            out[r] = fn(r)
+        except BaseException as e:                      # noqa: BLE001 -- reported below
+            errs[r] = e
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for e in errs:
+        if e is not None:
+            raise e
+    return out
+
+
+def slab_run(n, world, steps, v0, dt, src=None, ny=None, env=None):
+    """vort after `steps` steps of the world-rank model (rows concatenated), plus the ranks' plan."""
+    S = _slab()
+    ny = ny or n
+    hub = S.local_hub(world) if world > 1 else None
+    plan = {}
+
+    def rank_fn(r):
+        m = S.EngineSlab(n, ny, dt=dt, rank=r, world=world, transport=hub)
+        try:
+            plan[r] = (m.field_groups, m.row_chunks, m.KA, m.KF)
+            m.set_vort_local(S.local_rows(v0, r, world))
+            if src is not None:
+                m.set_source_local(S.local_rows(src, r, world))
+            back = m.vort_local().cpu().numpy()
+            m.step(steps)
+            return back, m.vort_local().cpu().numpy()
+        finally:
+            m.close()
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        res = run_ranks(world, rank_fn)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        if hub is not None:
+            S.local_hub_destroy(hub)
+    return np.concatenate([r[0] for r in res], axis=0), np.concatenate([r[1] for r in res], axis=0), plan[0]
+
+
+@pytest.mark.parametrize("world,n,steps,env", [
+    (1, 256, 3, None), (2, 256, 3, None), (4, 256, 2, None), (8, 512, 1, None), (2, 1024, 2, None), (4, 768, 2, None),
+    (4, 1024, 2, {"FB_SLAB_FIELD_GROUPS": "4", "FB_SLAB_ROW_CHUNKS": "4"}),       # finest pipelining on a small grid
+    (2, 512, 2, {"FB_SLAB_FIELD_GROUPS": "2", "FB_SLAB_ROW_CHUNKS": "8"}),
+])
+def test_engine_slab_matches_fused_path(world, n, steps, env):
     import xlab_fftbarotropic_amd as X
-    slab = import_module("xlab-fftbarotropic_amd.slab")
-    S = slab
     dt = 3.0
     v0 = X.make_field("elliptic", n)
     src = X.make_source_kuo2004(n)
     ref = X.Model(n, n, dt=dt)
     ref.set_vort(v0)
     ref.set_source(src)
+    back_want = ref.vort().cpu().numpy()
     ref.step(steps)
     want = ref.vort().cpu().numpy()
-
-    g = _Group(X, slab, n, world, dt)
-    for r, b in enumerate(g.be):
-        b.set_source(S.local_rows(src, r, world))
-        b.phase(S.PH_R2C_ROWS, real_in=b.to_device_real(S.local_rows(v0, r, world)))
-    g.xt()
-    g.ph(S.PH_R2C_COLS)
-    g.ph(S.PH_PRIME)
-    for _ in range(steps):
-        for k in range(4):
-            g.ph(S.PH_COL_BWD)
-            g.xw4()
-            g.ph(S.PH_ROW)
-            g.xt()
-            g.ph(S.PH_COL_FWD, stage=k)
-    g.ph(S.PH_C2R_COLS)
-    g.xt(reverse=True)
-    rows = []
-    for b in g.be:
-        out = b.empty_real()
-        b.phase(S.PH_C2R_ROWS, real_out=out)
-        rows.append(out.cpu().numpy())
-    got = np.concatenate(rows, axis=0)
-    torch.cuda.synchronize()
+    back, got, plan = slab_run(n, world, steps, v0, dt, src=src, env=env)
+    if env:
+        assert plan[0] == int(env["FB_SLAB_FIELD_GROUPS"]) and plan[1] <= int(env["FB_SLAB_ROW_CHUNKS"])
+    assert np.array_equal(back.view(np.uint32), back_want.view(np.uint32))            # set_vort / get_vort across the transposes
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-    for b in g.be:
-        b.close()
+
+
+def test_engine_slab_4096_uses_the_headline_row_kernel():
+    """ny = 4096 on 2 ranks: the slab row pass is k_row8 too (slab-blocked addressing); the column side is the
+    three-kernel path on both sides (FB_FULL_PASS=0 for the single-GPU reference) -> bit-identical."""
+    import subprocess
+    import sys
+    import tempfile
+    import xlab_fftbarotropic_amd as X
+    nx, ny, world, steps = 512, 4096, 2, 2
+    rng = np.random.default_rng(5)
+    v0 = (rng.standard_normal((nx, ny)) * 1e-4).astype(np.float32)
+    src = (rng.standard_normal((nx, ny)) * 1e-9).astype(np.float32)
+    _, got, _ = slab_run(nx, world, steps, v0, 0.75, src=src, ny=ny)
+    ref = X.Model(nx, ny, dt=0.75)                      # nx = 512: three-kernel column path, k_row8 row pass
+    ref.set_vort(v0)
+    ref.set_source(src)
+    ref.step(steps)
+    assert np.array_equal(got.view(np.uint32), ref.vort().cpu().numpy().view(np.uint32))
+
+
+def _invariants(v0, v1, with_source=False):
+    assert np.isfinite(v1).all()
+    m0, m1 = float(v0.astype(np.float64).mean()), float(v1.astype(np.float64).mean())
+    if not with_source:
+        assert abs(m1 - m0) <= 1e-6 * abs(m0) + 1e-12                               # (0,0) mode: exact in spectral space, fp32 sum here
+        e0, e1 = float((v0.astype(np.float64) ** 2).sum()), float((v1.astype(np.float64) ** 2).sum())
+        assert e1 <= e0 * (1 + 1e-6)                                                  # enstrophy does not grow
+
+
+def test_config4_8192_gaussian_on_4_ranks_full_size():
+    """BASELINE configs[3]: 8192 x 8192 gaussian vortex, dt = 3*1024/8192 s, ky slabs over 4 ranks -- full size.
+    One RK4 step: the 4-rank engine path against the fused single-GPU path (bit for bit), the oracle
+    (main-shallow-water.cpp:277-338 == main.cpp:259-317 for a zero source) and the invariants."""
+    import oracle_py as O
+    import ref_numpy as R
+    import xlab_fftbarotropic_amd as X
+    n, world, dt = 8192, 4, 3.0 * 1024 / 8192
+    v0 = X.make_field("gaussian", n)
+    assert np.array_equal(v0[::64, ::64], O.make_field("gaussian", n)[::64, ::64])
+    ref = X.Model(n, n, dt=dt)
+    ref.set_vort(v0)
+    s0 = ref.spectrum()[0, 0].item()
+    ref.step(1)
+    assert ref.spectrum()[0, 0].item() == s0                                          # mean vorticity conserved exactly
+    want = ref.vort().cpu().numpy()
+    del ref
+    back, got, plan = slab_run(n, world, 1, v0, dt)
+    assert plan == (4, 4, 976, 64)                                                    # 16 MB per peer and field: fully pipelined
+    assert R.rel_l2(back, v0) < 1e-6
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    _invariants(v0, got)
+    mo = O.Model(n, n, dt=dt)
+    mo.set_vort(v0)
+    mo.step(1)
+    assert R.rel_l2(got, mo.vort()) < 1e-5                                            # north-star bar, stated for 1000 steps
+
+
+def test_config5_16384_source_forced_on_8_ranks_full_size():
+    """BASELINE configs[4]: 16384 x 16384, the source-forced variant (main-shallow-water.cpp:277-338: Kuo2004 initial field
+    + the FIFO producer's cake of vort_src_input.cpp:35-46 switched on), dt = 3*1024/16384 s, ky slabs over 8 ranks --
+    full size (about 25 GB of HBM with the single-GPU reference model alongside).  One RK4 step: 8-rank engine path
+    against the fused single-GPU path bit for bit; invariants; the source really acts."""
+    import ref_numpy as R
+    import xlab_fftbarotropic_amd as X
+    n, world, dt = 16384, 8, 3.0 * 1024 / 16384
+    v0 = X.make_field("kuo2004", n)
+    src = X.make_source_kuo2004(n)
+    assert float(src.max()) > 0
+    ref = X.Model(n, n, dt=dt)
+    ref.set_vort(v0)
+    s0 = ref.spectrum()[0, 0].item()
+    ref.step(1)
+    assert ref.spectrum()[0, 0].item() == s0
+    unforced = ref.vort().cpu().numpy()
+    _invariants(v0, unforced)
+    ref.set_vort(v0)
+    ref.set_source(src)
+    ref.step(1)
+    want = ref.vort().cpu().numpy()
+    del ref
+    assert not np.array_equal(want, unforced)
+    gain = (want.astype(np.float64) - unforced.astype(np.float64)).sum() / (src.astype(np.float64).sum() * dt)
+    assert abs(gain - 1.0) < 1e-3                                                     # d(mean vort)/dt = mean source
+    back, got, plan = slab_run(n, world, 1, v0, dt, src=src)
+    assert plan == (4, 4, 976, 64)
+    assert R.rel_l2(back, v0) < 1e-6
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    _invariants(v0, got, with_source=True)
+
+
+def test_engine_slab_many_steps_stay_in_step():
+    """Ranks racing through 40 steps (160 stages, thousands of event hand-offs between 16 streams): any missing
+    dependency between a rank's compute and communication streams shows up as a bit difference."""
+    import xlab_fftbarotropic_amd as X
+    n, world, steps = 512, 4, 40
+    v0 = X.make_field("kuo2004", n)
+    ref = X.Model(n, n)
+    ref.set_vort(v0)
+    ref.step(steps)
+    _, got, _ = slab_run(n, world, steps, v0, 3.0, env={"FB_SLAB_FIELD_GROUPS": "4", "FB_SLAB_ROW_CHUNKS": "2"})
+    assert np.array_equal(got.view(np.uint32), ref.vort().cpu().numpy().view(np.uint32))
+
+
+def test_transport_selftests():
+    """fb_slab_transport_selftest through the in-process hub (4 ranks) and through RCCL with world = 1 and the own block
+    routed through grouped ncclSend/ncclRecv (FB_RCCL_SELF=1): library load, ncclCommInitRank, the grouped call path."""
+    import ctypes as C
+    import xlab_fftbarotropic_amd as X
+    S = _slab()
+    L = X.lib()
+    hub = S.local_hub(4)
+
+    def fn(r):
+        m = S.EngineSlab(256, rank=r, world=4, transport=hub)
+        bad = C.c_size_t(123)
+        X.package.binding.check(L.fb_slab_transport_selftest(m._h, 100003, C.byref(bad)))
+        m.close()
+        return bad.value
+    assert run_ranks(4, fn) == [0, 0, 0, 0]
+    S.local_hub_destroy(hub)
+    os.environ["FB_RCCL_SELF"] = "1"
+    try:
+        m = S.EngineSlab(256, rank=0, world=1)
+        idbuf = C.create_string_buffer(128)
+        X.package.binding.check(L.fb_slab_unique_id(idbuf))
+        X.package.binding.check(L.fb_slab_connect_rccl(m._h, idbuf))
+        bad = C.c_size_t(123)
+        X.package.binding.check(L.fb_slab_transport_selftest(m._h, 1 << 20, C.byref(bad)))
+        assert bad.value == 0
+        m.close()
+    finally:
+        os.environ.pop("FB_RCCL_SELF", None)
 
 
 def test_slab_model_world1_api():
-    """SlabModel with world == 1 (no process group) equals Model."""
-    from importlib import import_module
+    """SlabModel with world == 1 (no transport) equals Model."""
     import xlab_fftbarotropic_amd as X
-    slab = import_module("xlab-fftbarotropic_amd.slab")
+    S = _slab()
     n = 256
     v0 = X.make_field("gaussian", n)
-    m = slab.SlabModel(n, n, rank=0, world=1)
+    m = S.SlabModel(n, n, rank=0, world=1)
     m.set_vort_local(v0)
     m.step(4)
     ref = X.Model(n, n)
     ref.set_vort(v0)
     ref.step(4)
     assert np.array_equal(m.vort_local().cpu().numpy().view(np.uint32), ref.vort().cpu().numpy().view(np.uint32))
+    m.close()
 
 
 def _free_port():
@@ -110,15 +259,13 @@ def _free_port():
 
 
 def test_bench_two_ranks_on_one_gpu_gloo(tmp_path):
-    """The real multi-process flow of bench.py (torch.distributed.run, SlabModel + HipBackend, exchange
-    between phases) with 2 ranks sharing the GPU over gloo -- RCCL itself needs two devices."""
+    """The real multi-process flow of bench.py (torch.distributed.run, one EngineSlab per process, the callback transport
+    over gloo) with 2 ranks sharing the GPU -- RCCL itself needs two devices."""
     import json
-    import os
     import subprocess
     import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--grid", "512", "--backend", "gloo", "--cpu-steps", "0"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -127,12 +274,10 @@ def test_bench_two_ranks_on_one_gpu_gloo(tmp_path):
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "slab2"
 
 
-def test_slab_model_two_ranks_gloo_matches_single(tmp_path):
-    """SlabModel on 2 processes (one GPU, gloo) reproduces the single-process field bit for bit."""
-    import os
+def test_engine_slab_two_processes_gloo_matches_single(tmp_path):
+    """EngineSlab on 2 processes (one GPU, gloo callback transport) reproduces the single-process field bit for bit."""
     import subprocess
     import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "w.py"
     script.write_text(
         "import os, sys, numpy as np, torch, torch.distributed as dist\n"
@@ -145,7 +290,7 @@ def test_slab_model_two_ranks_gloo_matches_single(tmp_path):
         "v0 = X.make_field('elliptic', n)\n"
         "m = slab.SlabModel(n, n, rank=r, world=w); m.set_vort_local(slab.local_rows(v0, r, w)); m.step(3)\n"
         "np.save(os.path.join(%r, 'rows%%d.npy' %% r), m.vort_local().cpu().numpy())\n"
-        "dist.destroy_process_group()\n" % (root, str(tmp_path)))
+        "m.close(); dist.destroy_process_group()\n" % (ROOT, str(tmp_path)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)

@@ -391,6 +391,9 @@ def test_record_files_have_the_plotting_layout(tmp_path):
     assert abs(ix - (L / 2) / dx) <= 1 and abs(iy - (L / 2) / dx) <= 1     # strong vortex at the centre
     i_weak = int(round((L / 2 + 5e4) / dx))
     assert img[n // 2, i_weak] > 2.5e-3 and img[i_weak, n // 2] < 1e-4      # weak vortex: +x of the centre, not +y
-    v = np.fromfile(str(tmp_path / "output" / "v_step_0.bin"), dtype="<f4", count=n * n).reshape((n, n)).transpose()
-    j, r = n // 2, int(round(2e4 / dx))
-    assert v[j, n // 2 + r] > 5 and v[j, n // 2 - r] < -5                    # v = dpsi/dx: cyclonic flow, northward east of the core
+    u = np.fromfile(str(tmp_path / "output" / "u_step_0.bin"), dtype="<f4", count=n * n).reshape((n, n)).transpose()
+    c, r = n // 2, int(round(2e4 / dx))
+    # u = -dpsi/dy: both vortices sit on the line y = L/2, so u is antisymmetric ACROSS image rows (westward north of the
+    # cyclones, eastward south of them) and vanishes along the row through the centres
+    assert u[c + r, c] < -5 and u[c - r, c] > 5 and abs(u[c + r, c] + u[c - r, c]) < 1e-2
+    assert abs(u[c, c + r]) < 1e-2 and abs(u[c, c - r]) < 1e-2

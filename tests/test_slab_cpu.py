@@ -64,7 +64,7 @@ def _worker(rank, world, port, n, steps, with_src, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,steps,with_src", [(2, 64, 3, False), (2, 64, 2, True), (4, 64, 2, False)])
+@pytest.mark.parametrize("world,n,steps,with_src", [(2, 64, 3, False), (2, 64, 2, True), (4, 64, 2, False), (2, 256, 1, True)])
 def test_slab_exchange_matches_single_process(tmp_path, world, n, steps, with_src):
     port = _free_port()
     out = str(tmp_path / "err_%d.npy")
@@ -75,18 +75,41 @@ def test_slab_exchange_matches_single_process(tmp_path, world, n, steps, with_sr
         assert err < 1e-10, "rank %d: rel L2 %g" % (r, err)
 
 
-def test_slab_geometry_and_world1():
+def test_slab_geometry_plan_and_world1():
+    """Host logic of the decomposition, no GPU: slab.py's geometry and per-stage schedule against the engine's own
+    (fb_slab_geometry / fb_slab_plan in libfftbaro.so), the even split of the ACTIVE columns, and world == 1."""
+    import ctypes as C
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
     from importlib import import_module
     import ref_numpy as R
+    import xlab_fftbarotropic_amd as X
     from slab_numpy_backend import NumpyBackend
     slab = import_module("xlab-fftbarotropic_amd.slab")
-    assert slab.slab_geometry(4096, 4096, 1) == (4096, 2064)
-    assert slab.slab_geometry(4096, 4096, 8) == (512, 272)
-    assert slab.slab_geometry(16384, 16384, 8) == (2048, 1040)
-    assert slab.slab_geometry(8192, 8192, 4) == (2048, 1040)
+    L = X.lib()
+    # BASELINE configs 4 and 5, the headline grid on 2..8 ranks, a 3*2^k grid and a small one whose active slabs cover everything
+    cases = [(8192, 8192, 4), (16384, 16384, 8), (4096, 4096, 1), (4096, 4096, 2), (4096, 4096, 4), (4096, 4096, 8), (768, 768, 4), (64, 64, 8), (256, 1024, 2)]
+    for nx, ny, w in cases:
+        xl, ka, kf = C.c_int(), C.c_int(), C.c_int()
+        assert L.fb_slab_geometry(nx, ny, w, C.byref(xl), C.byref(ka), C.byref(kf)) == 0
+        assert (xl.value, ka.value, kf.value) == slab.slab_geometry(nx, ny, w), (nx, ny, w)
+        fg, ch, ops = slab.engine_plan(nx, ny, w)
+        assert (fg, ch) == slab.stage_plan(nx, ny, w) and ops == slab.stage_schedule(nx, ny, w), (nx, ny, w)
+        hy = ny // 2 + 1
+        assert w * ka.value + w * kf.value >= hy and ka.value % 16 == 0 and kf.value % 16 == 0
+        # every column inside the dealiasing circle lies in an active slab, and the last rank is not idle:
+        jmax = int(np.ceil(np.sqrt(2.0) * np.ceil(ny / 3.0))) if nx == ny else None
+        if jmax is not None:
+            assert w * ka.value >= jmax - 1
+            if jmax >= 16 * w:                                                 # (slabs are whole 16-column tiles)
+                assert (w - 1) * ka.value < jmax                               # active columns reach into the last rank's slab
+    assert slab.slab_geometry(8192, 8192, 4) == (2048, 976, 64)
+    assert slab.slab_geometry(16384, 16384, 8) == (2048, 976, 64)
+    assert slab.slab_geometry(4096, 4096, 8) == (512, 256, 16)
+    assert slab.stage_plan(8192, 8192, 4) == (4, 4) and slab.stage_plan(16384, 16384, 8) == (4, 4)
+    assert slab.stage_plan(4096, 4096, 8) == (2, 1) and slab.stage_plan(4096, 4096, 1) == (1, 1)
+    assert L.fb_slab_plan(1000, 1000, 2, None, None, None, 0) == 0             # unsupported grid
     n = 32
     rng = np.random.default_rng(0)
     v0 = 1e-3 * rng.standard_normal((n, n))

@@ -4,7 +4,10 @@ usage: profile_collect.py <tag> [grid]"""
 import json, os, shutil, sys
 tag = sys.argv[1]; n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", "prof_" + tag); dst = os.path.join(root, "profiles")
+src = os.path.join(root, "gpurun_out", "prof_%s_%d" % (tag, n)); dst = os.path.join(root, "profiles")
+import subprocess
+commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip()
+dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "xlab-fftbarotropic_amd", "bench.py"], stdout=subprocess.PIPE, text=True).stdout.strip())
 shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "%s_kernel_stats_%d.csv" % (tag, n)))
 line = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1]
 json.dump(json.loads(line), open(os.path.join(dst, "%s_bench_%d.json" % (tag, n)), "w"), indent=1)
@@ -13,7 +16,8 @@ P = 16 * ((n // 2 + 1 + 15) // 16)
 C = 8 * n * P                                   # one complex field at the un-tuned pitch
 out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --cpu-steps 0 (%d^2, separate passes)" % n,
        "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
-       "C_bytes": C, "kernels": {}}
+       "C_bytes": C, "kernels": {},
+       "commit": commit + ("+uncommitted changes" if dirty else ""), "note": "sources of the profiled run = this commit (the profile is collected before it is committed; '+uncommitted' = the working tree at collection time)"}
 for k, v in pmc.items():
     if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
         continue

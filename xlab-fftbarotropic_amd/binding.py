@@ -14,6 +14,8 @@ import numpy as np
 from . import build as _build
 
 _lib = None
+# fb_alltoall_fn (include/fftbaro.h): user, send, recv, stride, offset, count, hip stream
+ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p)
 
 
 class FftBaroError(RuntimeError):
@@ -83,9 +85,24 @@ def lib():
     L.fb_make_field.argtypes = [C.c_char_p, ip, ip, C.c_float, C.c_float, C.c_void_p]
     L.fb_make_source_kuo2004.argtypes = [ip, ip, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.fb_create_slab.argtypes = [C.POINTER(vp), ip, ip, C.c_float, C.c_float, ip, ip]
-    L.fb_slab_geometry.argtypes = [vp, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip), C.POINTER(C.c_size_t)]
-    L.fb_model_create_slab.argtypes = [C.POINTER(vp), vp, C.c_float, C.c_float, fp, fp, fp, fp]
-    L.fb_model_phase.argtypes = [vp, ip, ip, fp, fp]
+    L.fb_slab_unique_id.argtypes = [C.c_char_p]
+    L.fb_slab_create.argtypes = [C.POINTER(vp), ip, ip, C.c_float, C.c_float, C.c_float, C.c_float, ip, ip]
+    L.fb_slab_destroy.argtypes = [vp]
+    L.fb_slab_connect_rccl.argtypes = [vp, C.c_char_p]
+    L.fb_local_hub_create.argtypes = [C.POINTER(vp), ip]
+    L.fb_local_hub_destroy.argtypes = [vp]
+    L.fb_slab_connect_local.argtypes = [vp, vp]
+    L.fb_slab_connect_callback.argtypes = [vp, ALLTOALL_FN, vp]
+    L.fb_slab_set_vort_local.argtypes = [vp, fp]
+    L.fb_slab_set_source_local.argtypes = [vp, fp]
+    L.fb_slab_get_vort_local.argtypes = [vp, fp]
+    L.fb_slab_step.argtypes = [vp, ip]
+    L.fb_slab_synchronize.argtypes = [vp]
+    L.fb_slab_time_steps.argtypes = [vp, ip, C.POINTER(C.c_float)]
+    L.fb_slab_transport_selftest.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.fb_slab_info.argtypes = [vp] + [C.POINTER(ip)] * 7
+    L.fb_slab_geometry.argtypes = [ip, ip, ip] + [C.POINTER(ip)] * 3
+    L.fb_slab_plan.argtypes = [ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip), ip]
     L.fb_write_field.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
     L.fb_read_field.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
     _lib = L
@@ -100,7 +117,9 @@ EXPORTS = [
     "fb_model_create", "fb_model_destroy", "fb_model_set_vort", "fb_model_set_source", "fb_model_step",
     "fb_model_use_graph", "fb_model_get_vort", "fb_model_get_diag", "fb_model_get_spectrum", "fb_model_set_spectrum", "fb_model_info",
     "fb_model_time_steps", "fb_model_profile_steps", "fb_write_field", "fb_read_field", "fb_make_field", "fb_make_source_kuo2004",
-    "fb_create_slab", "fb_slab_geometry", "fb_model_create_slab", "fb_model_phase",
+    "fb_create_slab", "fb_slab_unique_id", "fb_slab_create", "fb_slab_destroy", "fb_slab_connect_rccl", "fb_local_hub_create",
+    "fb_local_hub_destroy", "fb_slab_connect_local", "fb_slab_connect_callback", "fb_slab_set_vort_local", "fb_slab_set_source_local",
+    "fb_slab_get_vort_local", "fb_slab_step", "fb_slab_synchronize", "fb_slab_time_steps", "fb_slab_transport_selftest", "fb_slab_info", "fb_slab_geometry", "fb_slab_plan",
     "fb_malloc_host", "fb_free_host", "fb_stream_create", "fb_stream_destroy", "fb_stream_synchronize", "fb_event_create",
     "fb_event_destroy", "fb_event_record", "fb_stream_wait_event", "fb_event_synchronize", "fb_memcpy_d2h_async",
 ]

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIBDIR = os.path.join(HERE, "lib")
 SRC = os.path.join(CSRC, "fftbaro.hip")
-SRC_HOST = [os.path.join(CSRC, "fb_fields.cpp"), os.path.join(CSRC, "fb_fieldio.cpp")]
+SRC_HOST = [os.path.join(CSRC, "fb_fields.cpp"), os.path.join(CSRC, "fb_fieldio.cpp"), os.path.join(CSRC, "fb_slab_comm.cpp")]
 LIB = os.path.join(LIBDIR, "libfftbaro.so")
 LIB_FIELDIO = os.path.join(LIBDIR, "libfieldio.so")
 LIB_FFTW = os.path.join(LIBDIR, "libfftw3f_fb.so")

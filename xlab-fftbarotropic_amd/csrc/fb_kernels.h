@@ -135,17 +135,27 @@ __global__ void __launch_bounds__(256) k_state_relayout(const cf *__restrict__ i
 // -------------------------------------------------------------------------------------------
 enum { ROW_FUSED = 0, ROW_INV = 1, ROW_FWD = 2 };
 
+// A mixed-space array as the row pass sees it: element (field, row, k), k = global ky in [0, ny/2].
+// One GPU: one segment of pitch ka.  Multi-GPU exchange buffers: the row is cut into ky slabs of `ka` columns
+// (the ACTIVE columns, ky < katot = world*ka, exchanged every RK stage) followed by slabs of `kf` columns (the
+// FROZEN columns beyond the dealiasing circle, SURVEY note N1, exchanged once); slab s of a segment lives sstr*
+// complex after slab 0.  Divisions by ka / kf are multiplications by mag* = floor(2^32/d) + 1 (exact for k*d < 2^32).
+struct RowView {
+    const cf *a, *f;        // segment bases (field 0): active / frozen
+    long fstrA, fstrF;      // field strides (complex)
+    long sstrA, sstrF;      // slab strides (complex); unused on one GPU
+    int ka, kf, katot;      // one GPU: ka = pitch
+    unsigned magA, magF;
+};
+
 struct RowArgs {
-    const cf *M;            // mixed-space inputs, field f at M + f*m_fstride     (FUSED: 4 fields, INV: 1)
-    long m_fstride;         // complex elements
-    int  ks;                // columns per slab (== pitch P on one GPU)
-    long m_sstride;         // slab stride (complex), 0 on one GPU
-    cf  *T;                 // mixed-space output (FUSED, FWD)
-    long t_sstride;
-    const float *src;       // vort_src (real [x][y]) or NULL             (FUSED)
-    const float *rin;       // real input  [x][y]                          (FWD)
-    float *rout;            // real output [x][y]                          (INV)
-    int nx;                 // local rows (even)
+    RowView M;              // mixed-space inputs                                   (FUSED: 4 fields, INV: 1)
+    RowView T;              // mixed-space output                                   (FUSED, FWD)
+    int t_frozen;           // multi-GPU: 1 = also store the frozen columns of T (FWD: the state); FUSED: 0, their tendency is masked
+    const float *src;       // vort_src (real [x][y]) or NULL                       (FUSED)
+    const float *rin;       // real input  [x][y]                                   (FWD)
+    float *rout;            // real output [x][y]                                   (INV)
+    int x0, nx;             // local rows [x0, x0 + nx), nx even (a row chunk of the pipelined multi-GPU step, else everything)
     float scale;            // 1/GRIDS (FUSED) ; 1/GRIDS or 1 (INV)
     const cf *tw_bwd, *tw_fwd;
 };
@@ -168,21 +178,26 @@ template <int N> struct RowCfg {
     static constexpr int MIN_WAVES = HALFX ? 3 : (THREADS == 256 ? 2 : (THREADS == 512 ? 2 : 4));
 };
 
-// element (row, k) of a mixed-space array; SLAB: the row is cut into ky slabs of ks columns that
-// live sstride apart (send/receive buffers of the multi-GPU transpose), else one pitch-ks array
+// element (field, row, k) of a mixed-space array (see RowView); SLAB = multi-GPU exchange buffer
 template <bool SLAB>
-FB_DEV const cf *row_ptr(const cf *base, int ks, long sstride, int row, int k)
+FB_DEV const cf *row_ptr(const RowView &v, int field, int row, int k)
 {
-    if (!SLAB) return base + (size_t)row * ks + k;
-    const int slab = k / ks;
-    return base + (size_t)slab * sstride + (size_t)row * ks + (k - slab * ks);
+    if (!SLAB) return v.a + (size_t)field * v.fstrA + (size_t)row * v.ka + k;
+    if (k < v.katot) {
+        const int s = (int)__umulhi((unsigned)k, v.magA);
+        return v.a + (size_t)field * v.fstrA + (size_t)s * v.sstrA + (size_t)row * v.ka + (k - s * v.ka);
+    }
+    const int kk = k - v.katot, s = (int)__umulhi((unsigned)kk, v.magF);
+    return v.f + (size_t)field * v.fstrF + (size_t)s * v.sstrF + (size_t)row * v.kf + (kk - s * v.kf);
 }
+// does column k of an output view get stored?  (multi-GPU fused pass: the frozen columns' tendency is never used)
+template <bool SLAB> FB_DEV bool row_keep(const RowView &v, int t_frozen, int k) { return !SLAB || t_frozen || k < v.katot; }
 
 // Hermitian-extend two half-spectrum rows A,B into Z = A_ext + i B_ext, straight into the first
 // backward stage's registers (SURVEY note N2: imaginary parts at k=0 and k=N/2 are ignored).
 // Thread t owns positions t + i*T: for i < 8 that is k itself, for i >= 8 the mirror of N - pos.
 template <int N, bool SLAB>
-FB_DEV void row_load_pair(cf *reg, int t, const cf *baseA, const cf *baseB, int rowA, int rowB, int ks, long sstride)
+FB_DEV void row_load_pair(cf *reg, int t, const RowView &v, int fA, int fB, int rowA, int rowB)
 {
     constexpr int T = N / 16, R0 = RowTw<N, false>::radix(0);
 #pragma unroll
@@ -190,11 +205,11 @@ FB_DEV void row_load_pair(cf *reg, int t, const cf *baseA, const cf *baseB, int 
         const int i = ord_i<R0>(e);
         if (i < 8) {
             const int k = t + i * T;
-            const cf a = *row_ptr<SLAB>(baseA, ks, sstride, rowA, k), b = *row_ptr<SLAB>(baseB, ks, sstride, rowB, k);
+            const cf a = *row_ptr<SLAB>(v, fA, rowA, k), b = *row_ptr<SLAB>(v, fB, rowB, k);
             reg[e] = (i == 0 && t == 0) ? cf_make(a.x, b.x) : cf_make(a.x - b.y, a.y + b.x);
         } else {
             const int k = (16 - i) * T - t;                 // in (0, N/2]; == N/2 only for t == 0, i == 8
-            const cf a = *row_ptr<SLAB>(baseA, ks, sstride, rowA, k), b = *row_ptr<SLAB>(baseB, ks, sstride, rowB, k);
+            const cf a = *row_ptr<SLAB>(v, fA, rowA, k), b = *row_ptr<SLAB>(v, fB, rowB, k);
             reg[e] = (i == 8 && t == 0) ? cf_make(a.x, b.x) : cf_make(a.x + b.y, b.x - a.y);
         }
     }
@@ -204,7 +219,7 @@ FB_DEV void row_load_pair(cf *reg, int t, const cf *baseA, const cf *baseB, int 
 // half spectra and store rows rowA,rowB of T.  Only the upper half (positions >= N/2) goes
 // through LDS: the mirror of k = t + i*T (i < 8) is position (16-i)*T - t.
 template <int N, bool SLAB>
-FB_DEV void row_store_pair(cf *lds, int t, const cf *reg, bool valid, cf *T_, int rowA, int rowB, int ks, long sstride)
+FB_DEV void row_store_pair(cf *lds, int t, const cf *reg, bool valid, const RowView &v, int t_frozen, int rowA, int rowB)
 {
     constexpr int T = N / 16, RL = RowTw<N, true>::radix(RowPlan<N>::S - 1);
     constexpr int HOFF = RowCfg<N>::HALFX ? N / 2 : 0;           // only positions >= N/2 go through LDS
@@ -223,11 +238,12 @@ FB_DEV void row_store_pair(cf *lds, int t, const cf *reg, bool valid, cf *T_, in
             const int k = t + i * T;
             const cf zk = reg[e];
             const cf zn = (i == 0 && t == 0) ? zk : lds_rd(&lds[lds_pad(N - k - HOFF)]);
-            st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, k)), cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)));
-            st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, k)), cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)));
-        } else if (i == 8 && t == 0) {                       // Nyquist: its own mirror
-            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, N / 2)) = cf_make(reg[e].x, 0.f);
-            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, N / 2)) = cf_make(reg[e].y, 0.f);
+            if (!row_keep<SLAB>(v, t_frozen, k)) continue;
+            st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(v, 0, rowA, k)), cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)));
+            st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(v, 0, rowB, k)), cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)));
+        } else if (i == 8 && t == 0 && row_keep<SLAB>(v, t_frozen, N / 2)) {      // Nyquist: its own mirror
+            *const_cast<cf *>(row_ptr<SLAB>(v, 0, rowA, N / 2)) = cf_make(reg[e].x, 0.f);
+            *const_cast<cf *>(row_ptr<SLAB>(v, 0, rowB, N / 2)) = cf_make(reg[e].y, 0.f);
         }
     }
 }
@@ -235,8 +251,7 @@ FB_DEV void row_store_pair(cf *lds, int t, const cf *reg, bool valid, cf *T_, in
 // ---- LDS-DMA prefetch of two half-spectrum rows into the group's staging area ----------------
 // stg[0..N/2) = row A (k = 0..N/2-1), stg[N/2..N) = row B; the Nyquist elements travel in registers.
 template <int N, bool SLAB>
-FB_DEV void row_dma_issue(cf *stg, int t, const cf *baseA, const cf *baseB, int rowA, int rowB, int ks, long sstride,
-                          cf &nyqA, cf &nyqB)
+FB_DEV void row_dma_issue(cf *stg, int t, const RowView &v, int fA, int fB, int rowA, int rowB, cf &nyqA, cf &nyqB)
 {
     constexpr int T = N / 16, NW = T >= 64 ? T / 64 : 1, CH = N / 256;   // waves per group, 1-KiB chunks per row (only used when T >= 64)
     const int w = t >> 6, lane = t & 63;
@@ -244,12 +259,12 @@ FB_DEV void row_dma_issue(cf *stg, int t, const cf *baseA, const cf *baseB, int 
     for (int c = 0; c < CH / NW; ++c) {
         const int ch = w + c * NW, k = ch * 128 + lane * 2;
         cf *dstA = stg + ch * 128, *dstB = stg + N / 2 + ch * 128;   // wave-uniform; the DMA adds lane*16 B
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(baseA, ks, sstride, rowA, k),
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(v, fA, rowA, k),
                                          (void __attribute__((address_space(3))) *)dstA, 16, 0, (FB_NT & 4) ? 2 : 0);
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(baseB, ks, sstride, rowB, k),
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(v, fB, rowB, k),
                                          (void __attribute__((address_space(3))) *)dstB, 16, 0, (FB_NT & 4) ? 2 : 0);
     }
-    if (t == 0) { nyqA = *row_ptr<SLAB>(baseA, ks, sstride, rowA, N / 2); nyqB = *row_ptr<SLAB>(baseB, ks, sstride, rowB, N / 2); }
+    if (t == 0) { nyqA = *row_ptr<SLAB>(v, fA, rowA, N / 2); nyqB = *row_ptr<SLAB>(v, fB, rowB, N / 2); }
 }
 
 // Hermitian extension from the staging area into the first backward stage's registers
@@ -306,14 +321,14 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
     __syncthreads();
 
 #ifdef FB_ROW_SAMEROW   /* timing experiment only: every workgroup works on rows 0,1 (no HBM traffic); results are wrong */
-    auto pair_of = [&](int it, bool &valid) { const int pr = (it * gridDim.x + blockIdx.x) * G + grp; valid = pr < npairs; return 0; };
+    auto pair_of = [&](int it, bool &valid) { const int pr = (it * gridDim.x + blockIdx.x) * G + grp; valid = pr < npairs; return a.x0; };
 #else
-    auto pair_of = [&](int it, bool &valid) { const int pr = (it * gridDim.x + blockIdx.x) * G + grp; valid = pr < npairs; return valid ? 2 * pr : 0; };
+    auto pair_of = [&](int it, bool &valid) { const int pr = (it * gridDim.x + blockIdx.x) * G + grp; valid = pr < npairs; return a.x0 + (valid ? 2 * pr : 0); };
 #endif
     cf nyqA = cf_make(0.f, 0.f), nyqB = nyqA;
     if (DMA && iters > 0) {                                   // prologue: phase 0 of the first pair
         bool v; const int x = pair_of(0, v);
-        row_dma_issue<N, SLAB>(stg, t, a.M, a.M + a.m_fstride, x, x, a.ks, a.m_sstride, nyqA, nyqB);
+        row_dma_issue<N, SLAB>(stg, t, a.M, 0, 1, x, x, nyqA, nyqB);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
@@ -339,9 +354,9 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
                     lds_barrier();
                     row_ext_from_stage<N>(reg, launder(t), stg, nyqA, nyqB);
                     lds_barrier();
-                    row_dma_issue<N, SLAB>(stg, launder(t), a.M + 2 * a.m_fstride, a.M + 3 * a.m_fstride, x, x, a.ks, a.m_sstride, nyqA, nyqB);
+                    row_dma_issue<N, SLAB>(stg, launder(t), a.M, 2, 3, x, x, nyqA, nyqB);
                 } else {
-                    row_load_pair<N, SLAB>(reg, launder(t), a.M, a.M + a.m_fstride, x, x, a.ks, a.m_sstride);
+                    row_load_pair<N, SLAB>(reg, launder(t), a.M, 0, 1, x, x);
                 }
                 rowfft<N, false>(lds, launder(t), twb, reg);
 #pragma unroll
@@ -354,9 +369,9 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
                     lds_barrier();
                     bool vn = true; int xn = x1;
                     if (r == 1) xn = (it + 1 < iters) ? pair_of(it + 1, vn) : -1;
-                    if (xn >= 0) row_dma_issue<N, SLAB>(stg, launder(t), a.M, a.M + a.m_fstride, xn, xn, a.ks, a.m_sstride, nyqA, nyqB);
+                    if (xn >= 0) row_dma_issue<N, SLAB>(stg, launder(t), a.M, 0, 1, xn, xn, nyqA, nyqB);
                 } else {
-                    row_load_pair<N, SLAB>(reg, launder(t), a.M + 2 * a.m_fstride, a.M + 3 * a.m_fstride, x, x, a.ks, a.m_sstride);
+                    row_load_pair<N, SLAB>(reg, launder(t), a.M, 2, 3, x, x);
                 }
                 rowfft<N, false>(lds, launder(t), twb, reg);
 #pragma unroll
@@ -388,9 +403,9 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
             if constexpr (SHARE) rowfft<N, true>(lds, launder(t), reinterpret_cast<const RowTwSrc<N, true, true> &>(twb), reg);   // main.cpp:237 (y part)
             else rowfft<N, true>(lds, launder(t), twf_own, reg);
             if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next pair's first rows have landed
-            row_store_pair<N, SLAB>(lds, launder(t), reg, valid, a.T, x0, x1, a.ks, a.t_sstride);
+            row_store_pair<N, SLAB>(lds, launder(t), reg, valid, a.T, a.t_frozen, x0, x1);
         } else {
-            row_load_pair<N, SLAB>(reg, launder(t), a.M, a.M, x0, x1, a.ks, a.m_sstride);
+            row_load_pair<N, SLAB>(reg, launder(t), a.M, 0, 0, x0, x1);
             rowfft<N, false>(lds, launder(t), twb, reg);
             if (valid) {
 #pragma unroll

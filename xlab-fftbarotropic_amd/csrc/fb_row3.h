@@ -24,27 +24,26 @@ template <int M> struct Row3Cfg {
 
 // Hermitian-extended packed spectrum value Z[k], 0 <= k < N, of the two half-spectrum rows A, B
 template <int N, bool SLAB>
-FB_DEV cf row3_z(const cf *baseA, const cf *baseB, int rowA, int rowB, int ks, long sstride, int k)
+FB_DEV cf row3_z(const RowView &v, int fA, int fB, int rowA, int rowB, int k)
 {
     const bool mirror = 2 * k > N;
     const int kk = mirror ? N - k : k;
-    const cf a = *row_ptr<SLAB>(baseA, ks, sstride, rowA, kk), b = *row_ptr<SLAB>(baseB, ks, sstride, rowB, kk);
+    const cf a = *row_ptr<SLAB>(v, fA, rowA, kk), b = *row_ptr<SLAB>(v, fB, rowB, kk);
     if (kk == 0 || 2 * kk == N) return cf_make(a.x, b.x);                     // Im ignored at k = 0 and k = N/2
     return mirror ? cf_make(a.x + b.y, b.x - a.y) : cf_make(a.x - b.y, a.y + b.x);
 }
 
 // backward input of sub-transform r: radix-3 over the spectrum thirds + twiddle, into the first stage's registers
 template <int M, bool SLAB>
-FB_DEV void row3_load(cf *reg, int r, int t, const cf *baseA, const cf *baseB, int rowA, int rowB, int ks, long sstride,
-                      const cf *__restrict__ twN)
+FB_DEV void row3_load(cf *reg, int r, int t, const RowView &v, int fA, int fB, int rowA, int rowB, const cf *__restrict__ twN)
 {
     constexpr int N = 3 * M, T = M / 16, R0 = RowTw<M, false>::radix(0);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int p0 = t + ord_i<R0>(e) * T;
-        cf z0 = row3_z<N, SLAB>(baseA, baseB, rowA, rowB, ks, sstride, p0);
-        cf z1 = row3_z<N, SLAB>(baseA, baseB, rowA, rowB, ks, sstride, p0 + M);
-        cf z2 = row3_z<N, SLAB>(baseA, baseB, rowA, rowB, ks, sstride, p0 + 2 * M);
+        cf z0 = row3_z<N, SLAB>(v, fA, fB, rowA, rowB, p0);
+        cf z1 = row3_z<N, SLAB>(v, fA, fB, rowA, rowB, p0 + M);
+        cf z2 = row3_z<N, SLAB>(v, fA, fB, rowA, rowB, p0 + 2 * M);
         fft3<+1>(z0, z1, z2);                                   // z_r = sum_j Z[p0 + M j] exp(+2 pi i r j / 3)
         const cf g = r == 0 ? z0 : (r == 1 ? z1 : z2);
         reg[e] = r == 0 ? g : cmulc(g, twN[r * p0]);            // * W_N^{-r p0}
@@ -53,7 +52,7 @@ FB_DEV void row3_load(cf *reg, int r, int t, const cf *baseA, const cf *baseB, i
 
 // forward output: twiddle, radix-3 combine across the three groups through LDS, untangle, store rows A, B of T
 template <int M, bool SLAB>
-FB_DEV void row3_store(cf *lds_pair, int r, int t, const cf *reg, bool valid, cf *T_, int rowA, int rowB, int ks, long sstride,
+FB_DEV void row3_store(cf *lds_pair, int r, int t, const cf *reg, bool valid, const RowView &v, int t_frozen, int rowA, int rowB,
                        const cf *__restrict__ twN)
 {
     constexpr int N = 3 * M, T = M / 16, LSTR = Row3Cfg<M>::LSTR, RL = RowTw<M, true>::radix(RowPlan<M>::S - 1);
@@ -75,13 +74,14 @@ FB_DEV void row3_store(cf *lds_pair, int r, int t, const cf *reg, bool valid, cf
         for (int i = 0; i < 8; ++i) {
             const int k = (r * 8 + i) * T + t;                  // all k in [0, N/2)
             const cf zk = zval(k), zn = k == 0 ? zk : zval(N - k);
-            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, k)) = cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, k)) = cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
+            if (!row_keep<SLAB>(v, t_frozen, k)) continue;
+            *const_cast<cf *>(row_ptr<SLAB>(v, 0, rowA, k)) = cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            *const_cast<cf *>(row_ptr<SLAB>(v, 0, rowB, k)) = cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x));
         }
-        if (r == 0 && t == 0) {                                 // Nyquist: its own mirror
+        if (r == 0 && t == 0 && row_keep<SLAB>(v, t_frozen, N / 2)) {      // Nyquist: its own mirror
             const cf z = zval(N / 2);
-            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowA, N / 2)) = cf_make(z.x, 0.f);
-            *const_cast<cf *>(row_ptr<SLAB>(T_, ks, sstride, rowB, N / 2)) = cf_make(z.y, 0.f);
+            *const_cast<cf *>(row_ptr<SLAB>(v, 0, rowA, N / 2)) = cf_make(z.x, 0.f);
+            *const_cast<cf *>(row_ptr<SLAB>(v, 0, rowB, N / 2)) = cf_make(z.y, 0.f);
         }
     }
 }
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(Row3Cfg<M>::THREADS) k_row3(RowArgs a, const c
     for (int it = 0; it < iters; ++it) {
         const int pr = (it * gridDim.x + blockIdx.x) * GP + gp;
         const bool valid = pr < npairs;
-        const int x0 = valid ? 2 * pr : 0, x1 = x0 + 1;
+        const int x0 = a.x0 + (valid ? 2 * pr : 0), x1 = x0 + 1;
         const int tl = launder(t);
         cf reg[16];
         if (MODE == ROW_FUSED) {
@@ -120,11 +120,11 @@ __global__ void __launch_bounds__(Row3Cfg<M>::THREADS) k_row3(RowArgs a, const c
             for (int rr = 0; rr < 2; ++rr) {
                 const int x = x0 + rr;
                 float zx[16], zy[16];
-                row3_load<M, SLAB>(reg, r, launder(t), a.M, a.M + a.m_fstride, x, x, a.ks, a.m_sstride, twN);
+                row3_load<M, SLAB>(reg, r, launder(t), a.M, 0, 1, x, x, twN);
                 row_fft<M, false>(lds, launder(t), twb, reg);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { zx[e] = reg[e].x * a.scale; zy[e] = reg[e].y * a.scale; }   // main.cpp:154,168
-                row3_load<M, SLAB>(reg, r, launder(t), a.M + 2 * a.m_fstride, a.M + 3 * a.m_fstride, x, x, a.ks, a.m_sstride, twN);
+                row3_load<M, SLAB>(reg, r, launder(t), a.M, 2, 3, x, x, twN);
                 row_fft<M, false>(lds, launder(t), twb, reg);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -147,9 +147,9 @@ __global__ void __launch_bounds__(Row3Cfg<M>::THREADS) k_row3(RowArgs a, const c
         if (MODE == ROW_FUSED || MODE == ROW_FWD) {
             if constexpr (C::SHARE) row_fft<M, true>(lds, launder(t), reinterpret_cast<const RowTwSrc<M, true, true> &>(twb), reg);
             else row_fft<M, true>(lds, launder(t), twf_own, reg);
-            row3_store<M, SLAB>(lds_pair, r, launder(t), reg, valid, a.T, x0, x1, a.ks, a.t_sstride, twN);
+            row3_store<M, SLAB>(lds_pair, r, launder(t), reg, valid, a.T, a.t_frozen, x0, x1, twN);
         } else {
-            row3_load<M, SLAB>(reg, r, launder(t), a.M, a.M, x0, x1, a.ks, a.m_sstride, twN);
+            row3_load<M, SLAB>(reg, r, launder(t), a.M, 0, 0, x0, x1, twN);
             row_fft<M, false>(lds, launder(t), twb, reg);
             if (valid) {
 #pragma unroll

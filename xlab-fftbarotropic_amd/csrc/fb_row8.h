@@ -109,20 +109,20 @@ FB_DEV void r8_fwd(cf *v, cf *xbuf, const Row8Tw &tw, int w, int l)
 // elements (also by DMA, one dword per lane: a register load here would be waited for on the spot by the one
 // wave that issues it, and the whole workgroup waits for that wave at the next barrier)
 template <bool SLAB>
-FB_DEV void r8_dma_issue(cf *stg, int t, const cf *baseA, const cf *baseB, int row, int ks, long sstride)
+FB_DEV void r8_dma_issue(cf *stg, int t, const RowView &v, int fA, int fB, int row)
 {
     constexpr int N = Row8::N;
     const int w = t >> 6, lane = t & 63;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int ch = w + c * 8, k = ch * 128 + lane * 2;        // 16 chunks of 1 KiB per row, two per wave
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(baseA, ks, sstride, row, k),
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(v, fA, row, k),
                                          (void __attribute__((address_space(3))) *)(stg + ch * 128), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(baseB, ks, sstride, row, k),
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(v, fB, row, k),
                                          (void __attribute__((address_space(3))) *)(stg + N / 2 + ch * 128), 16, 0, 0);
     }
     if (t < 4) {                                                  // lanes 0,1: A(N/2).x,.y  lanes 2,3: B(N/2).x,.y
-        const float *src = reinterpret_cast<const float *>(row_ptr<SLAB>(t < 2 ? baseA : baseB, ks, sstride, row, N / 2)) + (t & 1);
+        const float *src = reinterpret_cast<const float *>(row_ptr<SLAB>(v, t < 2 ? fA : fB, row, N / 2)) + (t & 1);
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src,
                                          (void __attribute__((address_space(3))) *)(stg + N), 4, 0, 0);
     }
@@ -179,13 +179,13 @@ __global__ void __launch_bounds__(512, 4) k_row8(RowArgs a, const cf *__restrict
     const int npairs = a.nx >> 1;
     const int iters = (npairs + gridDim.x - 1) / gridDim.x;
 #ifdef FB_ROW_SAMEROW   /* timing experiment only: every workgroup works on rows 0,1 (no HBM traffic); results are wrong */
-    auto pair_of = [&](int it, bool &valid) { const int pr = it * gridDim.x + blockIdx.x; valid = pr < npairs; return 0; };
+    auto pair_of = [&](int it, bool &valid) { const int pr = it * gridDim.x + blockIdx.x; valid = pr < npairs; return a.x0; };
 #else
-    auto pair_of = [&](int it, bool &valid) { const int pr = it * gridDim.x + blockIdx.x; valid = pr < npairs; return valid ? 2 * pr : 0; };
+    auto pair_of = [&](int it, bool &valid) { const int pr = it * gridDim.x + blockIdx.x; valid = pr < npairs; return a.x0 + (valid ? 2 * pr : 0); };
 #endif
     if (iters > 0) {
         bool v; const int x = pair_of(0, v);
-        r8_dma_issue<SLAB>(stg, t, a.M, a.M + a.m_fstride, x, a.ks, a.m_sstride);
+        r8_dma_issue<SLAB>(stg, t, a.M, 0, 1, x);
         R8_WAIT_ROWS();
     }
     for (int it = 0; it < iters; ++it) {
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(512, 4) k_row8(RowArgs a, const cf *__restrict
             lds_barrier();
             r8_ext(v, tt, stg);
             lds_barrier();
-            r8_dma_issue<SLAB>(stg, tt, a.M + 2 * a.m_fstride, a.M + 3 * a.m_fstride, x, a.ks, a.m_sstride);
+            r8_dma_issue<SLAB>(stg, tt, a.M, 2, 3, x);
             r8_bwd(v, xbuf, tw, wl, ll);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { zx[e] = v[e].x * a.scale; zy[e] = v[e].y * a.scale; }   // main.cpp:154,168
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(512, 4) k_row8(RowArgs a, const cf *__restrict
             lds_barrier();
             bool vn = true; int xn = x1;
             if (r == 1) xn = (it + 1 < iters) ? pair_of(it + 1, vn) : -1;
-            if (xn >= 0) r8_dma_issue<SLAB>(stg, tt, a.M, a.M + a.m_fstride, xn, a.ks, a.m_sstride);
+            if (xn >= 0) r8_dma_issue<SLAB>(stg, tt, a.M, 0, 1, xn);
             r8_bwd(v, xbuf, tw, wl, ll);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -253,12 +253,13 @@ __global__ void __launch_bounds__(512, 4) k_row8(RowArgs a, const cf *__restrict
                 const int k = tt + e * T;
                 const cf zk = v[e];
                 const cf zn = (e == 0 && tt == 0) ? zk : lds_rd(&xbuf[N / 2 - k]);            // Z[N - k] sits at N - k - N/2
-                st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(a.T, a.ks, a.t_sstride, x0, k)), cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)));
-                st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(a.T, a.ks, a.t_sstride, x1, k)), cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)));
+                if (!row_keep<SLAB>(a.T, a.t_frozen, k)) continue;
+                st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x0, k)), cf_make(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)));
+                st2<(FB_NT & 8) != 0>(const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x1, k)), cf_make(0.5f * (zk.y + zn.y), 0.5f * (zn.x - zk.x)));
             }
-            if (tt == 0) {                                         // Nyquist: its own mirror
-                *const_cast<cf *>(row_ptr<SLAB>(a.T, a.ks, a.t_sstride, x0, N / 2)) = cf_make(v[4].x, 0.f);
-                *const_cast<cf *>(row_ptr<SLAB>(a.T, a.ks, a.t_sstride, x1, N / 2)) = cf_make(v[4].y, 0.f);
+            if (tt == 0 && row_keep<SLAB>(a.T, a.t_frozen, N / 2)) {  // Nyquist: its own mirror
+                *const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x0, N / 2)) = cf_make(v[4].x, 0.f);
+                *const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x1, N / 2)) = cf_make(v[4].y, 0.f);
             }
         }
     }

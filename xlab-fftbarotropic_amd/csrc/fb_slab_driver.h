@@ -1,0 +1,364 @@
+// fb_slab_driver.h -- the multi-GPU RK4 step, driven from C (included by fftbaro.hip; C ABI: include/fftbaro.h, fb_slab_*).
+//
+// One process per GPU: physical / mixed fields are split by x rows (XL = nx/world per rank),
+// spectral fields by ky columns -- the ACTIVE columns (ky < world*KA, at least one mode inside the dealiasing circle)
+// evenly over the ranks, the FROZEN ones beyond them likewise (ColGroup, fftbaro.hip).  Per RK stage two all-to-all
+// transposes: the four derivative fields (columns -> rows) and the tendency (rows -> columns), active columns only; the
+// frozen columns' derivative fields cross the links once, at priming, and their tendency is never sent (it is masked,
+// SURVEY note N1).  No reference counterpart: the reference is single-process (main.cpp:259-323 is what one step computes).
+//
+// Schedule of one stage, compute stream S and communication stream C (events in between):
+//   S: backward strided x sub-pass of field group 0 | group 1 | ...            C: all-to-all(group 0) | all-to-all(group 1) ...
+//   S: row pass of row chunk 0 | chunk 1 | ...                                  C: all-to-all(tendency chunk 0) | chunk 1 ...
+//   S: forward x pass + RK update + derivatives (needs every row)
+// so the links are busy from the end of the first sub-pass to the arrival of the last tendency chunk, and only the
+// forward pass, the first sub-pass and the first row chunk are exposed.  The granularity adapts to the message size
+// (fb_slab_plan): below ~2 MB per peer and operation RCCL's per-operation latency costs more than the overlap gains.
+#pragma once
+#include "fb_transport.h"
+
+struct fb_slab {
+    fb_ctx *c;
+    fb_model *m;
+    fb_transport tp;
+    bool connected, owns_streams;
+    hipStream_t comp, comm;
+    hipEvent_t ev_f[4], ev_r[8], ev_w4, ev_t, ev_rows_done, ev_fwd_done, ev_misc[2];
+    int nfg, nch;               // field groups of the derivative exchange (1, 2 or 4), row chunks of the tendency exchange (1..8)
+    int step_ops;               // exchange operations issued per RK stage (diagnostics)
+};
+
+// ---- schedule (host logic, no GPU needed): how finely one stage's two transposes are pipelined ----
+#define FB_OP_COL_BWD   1       /* arg = field group */
+#define FB_OP_XCHG_W4   2       /* arg = field group */
+#define FB_OP_ROW       3       /* arg = row chunk   */
+#define FB_OP_XCHG_T    4       /* arg = row chunk   */
+#define FB_OP_COL_FWD   5
+static void slab_plan(int nx, int ny, int world, int *nfg, int *nch)
+{
+    const int dxw = (int)ceil(((double)(float)nx) / 3.0), dyw = (int)ceil(((double)(float)ny) / 3.0);
+    int jmax, KA, KF;
+    slab_split(ny, (double)(float)((double)dxw * dxw + (double)dyw * dyw), world, jmax, KA, KF);
+    const long XL = nx / world;
+    const double field_mb = (double)XL * KA * 8.0 / (1 << 20);       // one field, one peer
+    int fg = world == 1 ? 1 : (field_mb >= 2.0 ? 4 : (2 * field_mb >= 2.0 ? 2 : 1));
+    int ch = world == 1 ? 1 : (field_mb >= 8.0 ? 4 : (field_mb >= 4.0 ? 2 : 1));
+    if (const char *e = getenv("FB_SLAB_FIELD_GROUPS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) fg = v; }
+    if (const char *e = getenv("FB_SLAB_ROW_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 8) ch = v; }
+    while (ch > 1 && ((XL / ch) & 1 || XL % ch)) ch >>= 1;          // chunks are whole row pairs
+    *nfg = fg; *nch = ch;
+}
+
+extern "C" int fb_slab_plan(int nx, int ny, int world, int *field_groups, int *row_chunks, int *ops, int cap)
+{
+    if (!fb_size_supported(nx, ny) || world < 1 || !is_pow2(world) || nx / world < 2) { fail(FB_EINVAL, "fb_slab_plan: bad geometry"); return 0; }
+    int nfg, nch;
+    slab_plan(nx, ny, world, &nfg, &nch);
+    if (field_groups) *field_groups = nfg;
+    if (row_chunks) *row_chunks = nch;
+    int n = 0;
+    auto put = [&](int op, int arg) { if (ops && n < cap) ops[n] = op * 16 + arg; ++n; };
+    for (int g = 0; g < nfg; ++g) { put(FB_OP_COL_BWD, g); if (world > 1) put(FB_OP_XCHG_W4, g); }
+    for (int h = 0; h < nch; ++h) { put(FB_OP_ROW, h); if (world > 1) put(FB_OP_XCHG_T, h); }
+    put(FB_OP_COL_FWD, 0);
+    return n;                                              // number of operations of one RK stage (>= 0, not a status)
+}
+
+extern "C" int fb_slab_geometry(int nx, int ny, int world, int *rows_local, int *cols_active, int *cols_frozen)
+{
+    if (!fb_size_supported(nx, ny) || world < 1 || !is_pow2(world) || nx / world < 2) return fail(FB_EINVAL, "fb_slab_geometry: bad geometry");
+    const int dxw = (int)ceil(((double)(float)nx) / 3.0), dyw = (int)ceil(((double)(float)ny) / 3.0);
+    int jmax, KA, KF;
+    slab_split(ny, (double)(float)((double)dxw * dxw + (double)dyw * dyw), world, jmax, KA, KF);
+    if (rows_local) *rows_local = nx / world;
+    if (cols_active) *cols_active = KA;
+    if (cols_frozen) *cols_frozen = KF;
+    return FB_OK;
+}
+
+// ---- creation ----
+extern "C" int fb_slab_destroy(fb_slab *s)
+{
+    if (!s) return FB_OK;
+    if (s->comp) hipStreamSynchronize(s->comp);
+    if (s->comm) hipStreamSynchronize(s->comm);
+    if (s->connected && s->tp.destroy) s->tp.destroy(s->tp.self);
+    if (s->m) fb_model_destroy(s->m);
+    if (s->c) fb_destroy(s->c);
+    hipEvent_t *evs[] = {&s->ev_w4, &s->ev_t, &s->ev_rows_done, &s->ev_fwd_done, &s->ev_misc[0], &s->ev_misc[1]};
+    for (hipEvent_t *e : evs) if (*e) hipEventDestroy(*e);
+    for (auto &e : s->ev_f) if (e) hipEventDestroy(e);
+    for (auto &e : s->ev_r) if (e) hipEventDestroy(e);
+    if (s->owns_streams) { if (s->comp) hipStreamDestroy(s->comp); if (s->comm) hipStreamDestroy(s->comm); }
+    delete s;
+    return FB_OK;
+}
+
+extern "C" int fb_slab_create(fb_slab **out, int nx, int ny, float lx, float ly, float nu, float dt, int rank, int world)
+{
+    if (!out) return fail(FB_EINVAL, "fb_slab_create: out is NULL");
+    *out = nullptr;
+    fb_slab *s = new fb_slab();
+    memset(s, 0, sizeof(*s));
+    int rc = fb_create_slab(&s->c, nx, ny, lx, ly, rank, world);
+    if (rc) { delete s; return rc; }
+    auto bail = [&](int code) { fb_slab_destroy(s); return code; };
+    if (hipStreamCreateWithFlags(&s->comp, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s->comm, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(FB_EHIP, "fb_slab_create: cannot create streams"));
+    s->owns_streams = true;
+    s->c->stream = s->comp;
+    hipEvent_t *evs[] = {&s->ev_w4, &s->ev_t, &s->ev_rows_done, &s->ev_fwd_done, &s->ev_misc[0], &s->ev_misc[1], &s->ev_f[0], &s->ev_f[1], &s->ev_f[2],
+                         &s->ev_f[3], &s->ev_r[0], &s->ev_r[1], &s->ev_r[2], &s->ev_r[3], &s->ev_r[4], &s->ev_r[5], &s->ev_r[6], &s->ev_r[7]};
+    for (hipEvent_t *e : evs)
+        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(FB_EHIP, "fb_slab_create: cannot create events"));
+    if ((rc = model_create_impl(&s->m, s->c, nu, dt, true))) return bail(rc);
+    slab_plan(nx, ny, world, &s->nfg, &s->nch);
+    s->connected = world == 1;                             // nothing to connect on one rank
+    *out = s;
+    return FB_OK;
+}
+
+static int slab_connected(fb_slab *s, int rc)
+{
+    if (rc) return rc;
+    s->connected = true;
+    return FB_OK;
+}
+#define SLAB_CONNECT_GUARD(s) do { if (!(s)) return fail(FB_EINVAL, "slab NULL"); if ((s)->connected && (s)->c->world > 1) return fail(FB_EINVAL, "slab already connected"); } while (0)
+extern "C" int fb_slab_connect_rccl(fb_slab *s, const char *unique_id)
+{
+    SLAB_CONNECT_GUARD(s);
+    if (!unique_id) return fail(FB_EINVAL, "fb_slab_connect_rccl: NULL id");
+    return slab_connected(s, fb_transport_rccl(&s->tp, unique_id, s->c->rank, s->c->world));
+}
+extern "C" int fb_slab_connect_local(fb_slab *s, void *hub)
+{
+    SLAB_CONNECT_GUARD(s);
+    return slab_connected(s, fb_transport_local(&s->tp, hub, s->c->rank, s->c->world));
+}
+extern "C" int fb_slab_connect_callback(fb_slab *s, fb_alltoall_fn fn, void *user)
+{
+    SLAB_CONNECT_GUARD(s);
+    return slab_connected(s, fb_transport_callback(&s->tp, fn, user, s->c->rank, s->c->world));
+}
+
+extern "C" int fb_slab_info(fb_slab *s, int *rows_local, int *cols_active, int *cols_frozen, int *ky0_active, int *ky0_frozen,
+                            int *field_groups, int *row_chunks)
+{
+    if (!s) return fail(FB_EINVAL, "slab NULL");
+    const fb_ctx *c = s->c;
+    if (rows_local) *rows_local = c->XL;
+    if (cols_active) *cols_active = c->grp[0].ncols;
+    if (cols_frozen) *cols_frozen = c->ngroups > 1 ? c->grp[1].ncols : 0;
+    if (ky0_active) *ky0_active = c->grp[0].ky0;
+    if (ky0_frozen) *ky0_frozen = c->ngroups > 1 ? c->grp[1].ky0 : 0;
+    if (field_groups) *field_groups = s->nfg;
+    if (row_chunks) *row_chunks = s->nch;
+    return FB_OK;
+}
+
+// Exchanges a known pattern through the connected transport (world*count floats each way) and returns the number of wrong
+// words: a start-up check of the links, and the one-GPU test of the RCCL call path (world = 1 with FB_RCCL_SELF=1).
+__global__ void k_slab_pattern(float *buf, size_t count, int world, int rank, int check, unsigned long long *bad)
+{
+    const size_t n = (size_t)world * count;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / count);
+        const size_t j = i - (size_t)p * count;
+        // send: block p carries (sender, receiver = p, index); recv: block p must carry (sender = p, receiver = rank, index)
+        const float want = check ? (float)(p * 131 + rank * 17) + (float)(j % 1021) : (float)(rank * 131 + p * 17) + (float)(j % 1021);
+        if (!check) buf[i] = want; else if (buf[i] != want) atomicAdd(bad, 1ull);
+    }
+}
+extern "C" int fb_slab_transport_selftest(fb_slab *s, size_t count, size_t *wrong_words)
+{
+    if (!s || !wrong_words || count == 0) return fail(FB_EINVAL, "fb_slab_transport_selftest: bad argument");
+    if (!s->tp.alltoall) return fail(FB_EINVAL, "fb_slab_transport_selftest: no transport connected");
+    const int W = s->c->world;
+    float *snd = nullptr, *rcv = nullptr; unsigned long long *bad = nullptr, hbad = 0;
+    int rc = FB_OK;
+    if (hipMalloc((void **)&snd, W * count * sizeof(float)) != hipSuccess || hipMalloc((void **)&rcv, W * count * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&bad, sizeof(*bad)) != hipSuccess) rc = fail(FB_ENOMEM, "selftest allocation failed");
+    if (!rc) {
+        hipMemsetAsync(bad, 0, sizeof(*bad), s->comm);
+        hipMemsetAsync(rcv, 0xff, W * count * sizeof(float), s->comm);
+        hipLaunchKernelGGL(k_slab_pattern, dim3(256), dim3(256), 0, s->comm, snd, count, W, s->c->rank, 0, bad);
+        rc = s->tp.alltoall(s->tp.self, snd, rcv, count, 0, count, s->comm);
+        if (!rc) {
+            hipLaunchKernelGGL(k_slab_pattern, dim3(256), dim3(256), 0, s->comm, rcv, count, W, s->c->rank, 1, bad);
+            if (hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, s->comm) != hipSuccess || hipStreamSynchronize(s->comm) != hipSuccess)
+                rc = fail(FB_EHIP, "selftest: device error");
+        }
+    }
+    if (snd) hipFree(snd);
+    if (rcv) hipFree(rcv);
+    if (bad) hipFree(bad);
+    *wrong_words = (size_t)hbad;
+    return rc;
+}
+
+// ---- stream plumbing ----
+static int slab_after(hipStream_t waiter, hipStream_t producer, hipEvent_t ev)      // `waiter` continues behind what `producer` has queued so far
+{
+    HIPCHK(hipEventRecord(ev, producer));
+    HIPCHK(hipStreamWaitEvent(waiter, ev, 0));
+    return FB_OK;
+}
+// all-to-all on the communication stream; units are complex elements
+static int slab_xchg(fb_slab *s, const cf *send, cf *recv, size_t stride, size_t offset, size_t count)
+{
+    if (s->c->world == 1 || count == 0) return FB_OK;          // one rank: the passes hand over in place
+    ++s->step_ops;
+    return s->tp.alltoall(s->tp.self, (const float *)send, (float *)recv, 2 * stride, 2 * offset, 2 * count, s->comm);
+}
+#define SLAB_READY(s) do { if (!(s)) return fail(FB_EINVAL, "slab NULL"); if (!(s)->connected) return fail(FB_EINVAL, "slab model is not connected to a transport (fb_slab_connect_*)"); } while (0)
+
+// ---- state in / out ----
+extern "C" int fb_slab_set_vort_local(fb_slab *s, const float *d_rows)
+{
+    SLAB_READY(s);
+    if (!d_rows) return fail(FB_EINVAL, "fb_slab_set_vort_local: NULL");
+    fb_ctx *c = s->c; fb_model *m = s->m;
+    int rc;
+    // readField + fftwf_execute(p_fwd_vort), main.cpp:143-144,256: y transform of the local rows -> transpose -> x transform of the local columns
+    RowArgs a = row_args_base(c);
+    a.rin = d_rows;
+    a.T = c->world == 1 ? view_single(c, m->gb[0].t_send, 0) : view_slab(c, m->gb[0].t_send, m->gb[1].t_send, 1);
+    if ((rc = launch_row<ROW_FWD>(c, a))) return rc;
+    if ((rc = slab_after(s->comm, s->comp, s->ev_misc[0]))) return rc;
+    for (int g = 0; g < c->ngroups; ++g) {
+        const size_t blk = (size_t)c->XL * c->grp[g].ncols;
+        if ((rc = slab_xchg(s, m->gb[g].t_send, m->gb[g].t_recv, blk, 0, blk))) return rc;
+    }
+    if ((rc = slab_after(s->comp, s->comm, s->ev_misc[1]))) return rc;
+    for (int g = 0; g < c->ngroups; ++g) {
+        const ColGroup &G = c->grp[g];
+        if ((rc = launch_col_strided<-1>(c, G, m->gb[g].t_recv, 1, 0)) || (rc = launch_col_block<-1>(c, G, m->gb[g].t_recv, 1, 0))) return rc;
+        if ((rc = state_convert(c, G, m->gb[g].t_recv, m->gb[g].ZA, true))) return rc;
+    }
+    m->primed = 0;
+    return FB_OK;
+}
+
+extern "C" int fb_slab_set_source_local(fb_slab *s, const float *d_rows)
+{
+    if (!s) return fail(FB_EINVAL, "slab NULL");
+    return fb_model_set_source(s->m, d_rows);               // this rank's [XL][ny] rows of vort_src (main-shallow-water.cpp:304), NULL = zeros
+}
+
+extern "C" int fb_slab_get_vort_local(fb_slab *s, float *d_rows)
+{
+    SLAB_READY(s);
+    if (!d_rows) return fail(FB_EINVAL, "fb_slab_get_vort_local: NULL");
+    fb_ctx *c = s->c; fb_model *m = s->m;
+    int rc;
+    // record path, main.cpp:273-281: copy of vort_c, x transform of the local columns -> transpose (reverse roles) -> y transform of the local rows
+    for (int g = 0; g < c->ngroups; ++g) {
+        const ColGroup &G = c->grp[g];
+        if ((rc = state_convert(c, G, m->gb[g].ZA, m->gb[g].t_recv, false))) return rc;
+        if ((rc = launch_col_block<+1>(c, G, m->gb[g].t_recv, 1, 0)) || (rc = launch_col_strided<+1>(c, G, m->gb[g].t_recv, 1, 0))) return rc;   // natural [x][ncols] == [dst][XL][ncols]
+    }
+    if ((rc = slab_after(s->comm, s->comp, s->ev_misc[0]))) return rc;
+    for (int g = 0; g < c->ngroups; ++g) {
+        const size_t blk = (size_t)c->XL * c->grp[g].ncols;
+        if ((rc = slab_xchg(s, m->gb[g].t_recv, m->gb[g].t_send, blk, 0, blk))) return rc;
+    }
+    if ((rc = slab_after(s->comp, s->comm, s->ev_misc[1]))) return rc;
+    RowArgs a = row_args_base(c);
+    a.M = c->world == 1 ? view_single(c, m->gb[0].t_send, 0) : view_slab(c, m->gb[0].t_send, m->gb[1].t_send, 1);
+    a.rout = d_rows; a.scale = 1.0f / (float)((size_t)c->nx * c->ny);
+    return launch_row<ROW_INV>(c, a);
+}
+
+// ---- the step ----
+static int slab_prime(fb_slab *s)
+{
+    fb_ctx *c = s->c; fb_model *m = s->m;
+    int rc;
+    if ((rc = model_prime(m))) return rc;                   // derivatives of every column; backward x pass finished on the frozen tiles
+    if (c->ngroups > 1) {                                   // the frozen columns' four fields cross the links once and stay in w4_recv
+        const size_t blk = 4 * (size_t)c->XL * c->grp[1].ncols;
+        if ((rc = slab_after(s->comm, s->comp, s->ev_misc[0]))) return rc;
+        if ((rc = slab_xchg(s, m->gb[1].w4_send, m->gb[1].w4_recv, blk, 0, blk))) return rc;
+        if ((rc = slab_after(s->comp, s->comm, s->ev_misc[1]))) return rc;
+    }
+    return FB_OK;
+}
+
+static int slab_stage(fb_slab *s, int stage)
+{
+    fb_ctx *c = s->c; fb_model *m = s->m;
+    GroupBufs &B = m->gb[0];
+    const size_t fld = (size_t)c->XL * c->grp[0].ncols;     // one field's block for one peer
+    int rc;
+    // derivative fields: finish the backward x pass on the active tiles, field group by field group, and ship each group
+    // while the next one is being transformed
+    for (int g = 0; g < s->nfg; ++g) {
+        const int f0 = 4 * g / s->nfg, f1 = 4 * (g + 1) / s->nfg;
+        if ((rc = model_col_bwd_active(m, f0, f1))) return rc;
+        if (c->world > 1) {
+            if ((rc = slab_after(s->comm, s->comp, s->ev_f[g]))) return rc;
+            if (g == 0) HIPCHK(hipStreamWaitEvent(s->comm, s->ev_rows_done, 0));          // the previous stage's row pass is done reading w4_recv
+            if ((rc = slab_xchg(s, B.w4_send, B.w4_recv, 4 * fld, f0 * fld, (f1 - f0) * fld))) return rc;
+        }
+    }
+    m->primed = 2;
+    if (c->world > 1 && (rc = slab_after(s->comp, s->comm, s->ev_w4))) return rc;
+    // row pass (main.cpp:154-237, y part) in row chunks; each chunk's tendency rows leave while the next chunk is computed
+    const int rows = c->XL / s->nch;
+    for (int h = 0; h < s->nch; ++h) {
+        if ((rc = launch_row<ROW_FUSED>(c, fused_row_args(m, h * rows, rows)))) return rc;
+        if (c->world > 1) {
+            if ((rc = slab_after(s->comm, s->comp, s->ev_r[h]))) return rc;
+            if (h == 0) HIPCHK(hipStreamWaitEvent(s->comm, s->ev_fwd_done, 0));           // the previous forward pass is done with t_recv
+            if ((rc = slab_xchg(s, B.t_send, B.t_recv, fld, (size_t)h * rows * c->grp[0].ncols, (size_t)rows * c->grp[0].ncols))) return rc;
+        }
+    }
+    HIPCHK(hipEventRecord(s->ev_rows_done, s->comp));
+    if (c->world > 1 && (rc = slab_after(s->comp, s->comm, s->ev_t))) return rc;
+    // forward x pass, viscosity, mask, RK stage update, derivatives of the new stage state (main.cpp:148,179-212,237-251,296-312)
+    if ((rc = model_col_fwd(m, stage))) return rc;
+    HIPCHK(hipEventRecord(s->ev_fwd_done, s->comp));
+    return FB_OK;
+}
+
+extern "C" int fb_slab_step(fb_slab *s, int nsteps)
+{
+    SLAB_READY(s);
+    if (nsteps < 0) return fail(FB_EINVAL, "fb_slab_step: nsteps < 0");
+    if (nsteps == 0) return FB_OK;
+    int rc;
+    if (!s->m->primed) {
+        if ((rc = slab_prime(s))) return rc;
+        HIPCHK(hipEventRecord(s->ev_rows_done, s->comp));
+        HIPCHK(hipEventRecord(s->ev_fwd_done, s->comp));
+    }
+    for (int n = 0; n < nsteps; ++n)
+        for (int k = 0; k < 4; ++k)                         // main.cpp:288-317
+            if ((rc = slab_stage(s, k))) return rc;
+    return FB_OK;
+}
+
+extern "C" int fb_slab_synchronize(fb_slab *s)
+{
+    if (!s) return fail(FB_EINVAL, "slab NULL");
+    HIPCHK(hipStreamSynchronize(s->comp));
+    HIPCHK(hipStreamSynchronize(s->comm));
+    return FB_OK;
+}
+
+// wall time of `nsteps` steps on this rank's compute stream (HIP events); the caller takes the maximum over ranks
+extern "C" int fb_slab_time_steps(fb_slab *s, int nsteps, float *total_ms)
+{
+    SLAB_READY(s);
+    if (!total_ms) return fail(FB_EINVAL, "fb_slab_time_steps: NULL");
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, s->comp));
+    int rc = fb_slab_step(s, nsteps);
+    HIPCHK(hipEventRecord(e1, s->comp));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(total_ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return rc;
+}

@@ -5,7 +5,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fftbaro.h"
@@ -51,10 +54,22 @@ extern "C" int fb_size_supported(int nx, int ny) { return size_ok(nx) && size_ok
 // --------------------------------------------------------------------------------------------
 // context
 // --------------------------------------------------------------------------------------------
+// A set of local ky columns with a pitch of its own.  One GPU: one group holding every column.  Multi-GPU: group 0 =
+// this rank's slab of the ACTIVE columns (ky < world*KA: at least one mode inside the dealiasing circle, exchanged every
+// RK stage), group 1 = its slab of the FROZEN columns beyond them (SURVEY note N1: their state never changes, so their
+// derivative fields cross the links once, at priming).
+struct ColGroup {
+    int ncols;                  // local columns == pitch of every array of the group (multiple of 16)
+    int ky0;                    // global ky of local column 0
+    int nct_active;             // 16-column tiles that contain at least one unmasked ky
+};
+
 struct fb_ctx {
-    int world, rank;            // slab decomposition: this process owns x rows [rank*XL, (rank+1)*XL) and
-    int XL, ky0;                //   ky columns [ky0, ky0+P); world == 1: everything
-    int nx, ny, hy, P;          // P = pitch of the private layouts (complex) == columns per slab
+    int world, rank;            // slab decomposition: this process owns x rows [rank*XL, (rank+1)*XL)
+    int XL;
+    int ngroups; ColGroup grp[2];
+    int KA, KF, katot;          // world > 1: columns per rank of the active / frozen slabs, katot = world*KA
+    int nx, ny, hy, P;          // P = grp[0].ncols: pitch of the private layouts on one GPU
     int N1, N2;                 // nx = N1*N2
     float lx, ly;
     hipStream_t stream;
@@ -68,12 +83,12 @@ struct fb_ctx {
     int col_streams;            // ... round-robin over this many streams, so that one chunk's kernel tails are filled by the next chunk
     hipStream_t aux[3];         // the extra streams (created on demand) and the fork/join events
     hipEvent_t ev_fork, ev_join[3];
-    int nct_active;             // local column tiles that contain at least one unmasked ky (the rest is frozen forever)
     bool nyq_frozen;            // the ky = ny/2 column lies outside the dealiasing circle (always on square grids)
     cf *d_scratch;              // nx*P complex, lazily allocated (standalone r2c / c2r)
     // host copies of the 1-D tables (fb_get_tables)
     std::vector<float> h_gx, h_gy; std::vector<double> h_kx2, h_ky2;
     int max_wg;                 // grid cap (persistent-style grids)
+    int dev;                    // HIP device the context lives on
 };
 
 static void split_nx(int nx, int &N1, int &N2)
@@ -166,12 +181,25 @@ static int autotune_pitch(fb_ctx *c);
 
 extern "C" int fb_create(fb_ctx **out, int nx, int ny, float lx, float ly) { return fb_create_slab(out, nx, ny, lx, ly, 0, 1); }
 
+static int round16(int v) { return (v + 15) / 16 * 16; }
+
+// columns per rank of the active and frozen slabs (must match slab.py: slab_geometry)
+static void slab_split(int ny, double gws, int world, int &jmax, int &KA, int &KF)
+{
+    const int hy = ny / 2 + 1;
+    jmax = 0;                                              // first ky with ky^2 >= gws: that column and all beyond are masked (fftwfop.cpp:57-61)
+    while (jmax < hy && (double)jmax * (double)jmax < gws) ++jmax;
+    KA = round16((jmax + world - 1) / world);
+    const int nf = hy - world * KA;
+    KF = nf > 0 ? round16((nf + world - 1) / world) : 0;
+}
+
 extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, int rank, int world)
 {
     if (!out) return fail(FB_EINVAL, "fb_create: out is NULL");
     *out = nullptr;
-    if (world < 1 || rank < 0 || rank >= world || !is_pow2(world) || (nx / world) < 2)
-        return fail(FB_EINVAL, "fb_create_slab: world must be a power of two with nx/world >= 2, 0 <= rank < world");
+    if (world < 1 || rank < 0 || rank >= world || !is_pow2(world) || (nx / world) < 2 || ((nx / world) & 1))
+        return fail(FB_EINVAL, "fb_create_slab: world must be a power of two with an even nx/world >= 2, 0 <= rank < world");
     if (!fb_size_supported(nx, ny))
         return fail(FB_EUNSUPPORTED, "fb_create: nx, ny must be powers of two in [64, 16384] or 3*2^k in [192, 3072]");
     if (!(lx > 0.f) || !(ly > 0.f)) return fail(FB_EINVAL, "fb_create: Lx, Ly must be positive");
@@ -179,43 +207,49 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(FB_EHIP, "fb_create: no HIP device (this engine has no CPU fallback)");
 
-    fb_ctx *c = new fb_ctx();
+    fb_ctx *c = new fb_ctx();                              // value-initialised: every pointer NULL, so fb_destroy() is safe on any error path below
     c->nx = nx; c->ny = ny; c->hy = ny / 2 + 1;
     c->world = world; c->rank = rank; c->XL = nx / world;
-    c->P = (c->hy + 16 * world - 1) / (16 * world) * 16;       // columns per slab, multiple of 16
-    if (const char *e = getenv("FB_PITCH_EXTRA")) c->P += 16 * atoi(e);   // tuning hook (disables the autotuner below)
-    c->ky0 = rank * c->P;
-    const int Ptot = (c->P + 64) * world;          // room for the pitch candidates of autotune_pitch()
     split_nx(nx, c->N1, c->N2);
     c->lx = lx; c->ly = ly; c->stream = nullptr; c->d_scratch = nullptr;
 
     // ---- coefficient tables: fftwfop.cpp:5-79 ----
     const float TWOPI = (float)(acosf(-1.0f) * 2.0f);                  // fftwfop.hpp:7
     const int hx = nx / 2 + 1;
+    const int dxw = (int)ceil(((double)(float)nx) / 3.0), dyw = (int)ceil(((double)(float)ny) / 3.0);   // :11-12
+    c->gws = (double)(float)((double)dxw * dxw + (double)dyw * dyw);              // :57
+    int jmax = 0;
+    slab_split(ny, c->gws, world, jmax, c->KA, c->KF);
+    int Ptot;                                              // table length: every global ky a local column can map to
+    if (world == 1) {
+        c->P = round16(c->hy);
+        if (const char *e = getenv("FB_PITCH_EXTRA")) c->P += 16 * atoi(e);   // tuning hook (disables the autotuner below)
+        c->ngroups = 1; c->grp[0] = ColGroup{c->P, 0, 0};
+        c->KA = c->P; c->KF = 0; c->katot = c->P;
+        Ptot = c->P + 64;                                  // room for the pitch candidates of autotune_pitch()
+    } else {
+        c->katot = world * c->KA;
+        c->ngroups = c->KF > 0 ? 2 : 1;
+        c->grp[0] = ColGroup{c->KA, rank * c->KA, 0};
+        c->grp[1] = ColGroup{c->KF, c->katot + rank * c->KF, 0};
+        c->P = c->KA;
+        Ptot = c->katot + world * c->KF + 16;
+    }
     c->h_gx.assign(nx, 0.f); c->h_kx2.assign(nx, 0.0); c->h_gy.assign(Ptot, 0.f); c->h_ky2.assign(Ptot, 0.0);
     for (int i = 0; i < hx; ++i) c->h_gx[i] = TWOPI * ((float)i) / lx;            // :15-17
     for (int i = hx; i < nx; ++i) c->h_gx[i] = -c->h_gx[nx - i];                  // :18-20
     for (int j = 0; j < c->hy; ++j) c->h_gy[j] = TWOPI * ((float)j) / ly;         // :22-24
     for (int i = 0; i < nx; ++i) c->h_kx2[i] = (double)c->h_gx[i] * (double)c->h_gx[i];
     for (int j = 0; j < c->hy; ++j) c->h_ky2[j] = (double)c->h_gy[j] * (double)c->h_gy[j];
-    const int dxw = (int)ceil(((double)(float)nx) / 3.0), dyw = (int)ceil(((double)(float)ny) / 3.0);   // :11-12
-    c->gws = (double)(float)((double)dxw * dxw + (double)dyw * dyw);              // :57
 
     c->nyq_frozen = ((double)(ny / 2) * (double)(ny / 2) >= c->gws);
-    {   // first ky with ky^2 >= gws: every mode of that column and beyond is masked (fftwfop.cpp:57-61)
-        int jmax = 0;
-        while (jmax < c->hy && (double)jmax * (double)jmax < c->gws) ++jmax;
-        int act = (jmax - c->ky0 + 15) / 16;
-        c->nct_active = act < 0 ? 0 : (act > c->P / 16 ? c->P / 16 : act);
-        if (getenv("FB_NO_COLUMN_SKIP")) c->nct_active = c->P / 16;
-        c->col_chunks = 1;
-        c->pace_strided = 0;      // measured: only pays at the unlucky pitch 16*129; off by default (FB_PACE=1 to try)
-        if (const char *e = getenv("FB_PACE")) c->pace_strided = atoi(e) != 0;
-        if (const char *e = getenv("FB_COL_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 16) c->col_chunks = v; }
-        c->col_streams = 1;
-        if (const char *e = getenv("FB_COL_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->col_streams = v; }
-        if (c->col_streams > c->col_chunks) c->col_streams = c->col_chunks;
-    }
+    c->col_chunks = 1;
+    c->pace_strided = 0;      // measured: only pays at the unlucky pitch 16*129; off by default (FB_PACE=1 to try)
+    if (const char *e = getenv("FB_PACE")) c->pace_strided = atoi(e) != 0;
+    if (const char *e = getenv("FB_COL_CHUNKS")) { int v = atoi(e); if (v >= 1 && v <= 16) c->col_chunks = v; }
+    c->col_streams = 1;
+    if (const char *e = getenv("FB_COL_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= 4) c->col_streams = v; }
+    if (c->col_streams > c->col_chunks) c->col_streams = c->col_chunks;
     int rc;
     if ((rc = upload(&c->d_gx, c->h_gx)) || (rc = upload(&c->d_kx2, c->h_kx2)) ||
         (rc = upload(&c->d_gy, c->h_gy)) || (rc = upload(&c->d_ky2, c->h_ky2)) ||
@@ -223,15 +257,14 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
         (rc = upload(&c->d_tw_big, make_root_table(nx))) || (rc = upload(&c->d_tw_256, make_root_table(256))) ||
         (rc = upload(&c->d_tw_row_bwd, make_row_table(ny % 3 ? ny : ny / 3, plan_radices_rt(ny % 3 ? ny : ny / 3, false)))) ||
         (rc = upload(&c->d_tw_row_fwd, make_row_table(ny % 3 ? ny : ny / 3, plan_radices_rt(ny % 3 ? ny : ny / 3, true))))) {
-        delete c; return rc;
+        fb_destroy(c); return rc;
     }
-    c->d_tw_row3 = nullptr;
-    if ((ny % 3 == 0 || ny == 4096) && (rc = upload(&c->d_tw_row3, make_root_table(ny)))) { delete c; return rc; }   // 4096: k_row8's W_ny^j
+    if ((ny % 3 == 0 || ny == 4096) && (rc = upload(&c->d_tw_row3, make_root_table(ny)))) { fb_destroy(c); return rc; }   // 4096: k_row8's W_ny^j
     c->use_row8 = ny == 4096 && !getenv("FB_NO_ROW8");
     hipDeviceProp_t prop;
-    int dev = 0;
-    HIPCHK(hipGetDevice(&dev));
-    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    if (hipGetDevice(&c->dev) != hipSuccess || hipGetDeviceProperties(&prop, c->dev) != hipSuccess) {
+        fb_destroy(c); return fail(FB_EHIP, "fb_create: cannot query the device");
+    }
     c->max_wg = prop.multiProcessorCount * 8;
     if ((rc = autotune_pitch(c))) { fb_destroy(c); return rc; }
     *out = c;
@@ -241,9 +274,8 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
 extern "C" int fb_destroy(fb_ctx *c)
 {
     if (!c) return FB_OK;
-    hipFree(c->d_gx); hipFree(c->d_kx2); hipFree(c->d_gy); hipFree(c->d_ky2);
-    hipFree(c->d_tw_n1); hipFree(c->d_tw_n2); hipFree(c->d_tw_big); hipFree(c->d_tw_row_bwd); hipFree(c->d_tw_row_fwd); hipFree(c->d_tw_256);
-    if (c->d_tw_row3) hipFree(c->d_tw_row3);
+    void *tabs[] = {c->d_gx, c->d_kx2, c->d_gy, c->d_ky2, c->d_tw_n1, c->d_tw_n2, c->d_tw_big, c->d_tw_row_bwd, c->d_tw_row_fwd, c->d_tw_256, c->d_tw_row3};
+    for (void *t : tabs) if (t) hipFree(t);
     if (c->d_scratch) hipFree(c->d_scratch);
     for (int i = 0; i < 3; ++i) { if (c->aux[i]) hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]); }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -421,6 +453,17 @@ extern "C" int fb_spec_rk4_combine(fb_ctx *c, const float *base, const float *k1
 // --------------------------------------------------------------------------------------------
 // FFT pass launchers
 // --------------------------------------------------------------------------------------------
+// hipFuncSetAttribute is per device: remember which (kernel, device) pairs are done
+static int set_max_lds(const fb_ctx *c, const void *fn, size_t bytes)
+{
+    static std::mutex mu; static std::set<std::pair<const void *, int>> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({fn, c->dev})) return FB_OK;
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done.insert({fn, c->dev});
+    return FB_OK;
+}
+
 template <int N, int MODE> static int launch_row_t(fb_ctx *c, const RowArgs &a)
 {
     using C = RowCfg<N>;
@@ -429,15 +472,12 @@ template <int N, int MODE> static int launch_row_t(fb_ctx *c, const RowArgs &a)
     int cap = c->max_wg / 2;                  // persistent-style grid: a few workgroups per CU, each loops over row pairs
     if (const char *e = getenv("FB_ROW_GRID")) { int v = atoi(e); if (v >= 64) cap = v; }
     if (grid > cap) grid = cap;
-    const bool slab = a.m_sstride != 0 || a.t_sstride != 0;
+    const bool slab = c->world > 1;
     auto kern = slab ? k_row<N, MODE, true> : k_row<N, MODE, false>;
-    static bool attr_set[2] = {false, false};
     static size_t lds_extra = 0;              // experiment hook: FB_ROW_LDS_EXTRA=<bytes> lowers the workgroups per CU
-    if (!attr_set[slab]) {
-        if (const char *e = getenv("FB_ROW_LDS_EXTRA")) lds_extra = (size_t)atol(e);
-        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C::LDS_BYTES + lds_extra)));
-        attr_set[slab] = true;
-    }
+    if (const char *e = getenv("FB_ROW_LDS_EXTRA")) lds_extra = (size_t)atol(e);
+    int rc = set_max_lds(c, (const void *)kern, C::LDS_BYTES + lds_extra);
+    if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES + lds_extra, c->stream, a);
     HIPCHK(hipGetLastError());
     return FB_OK;
@@ -449,7 +489,7 @@ template <int M, int MODE> static int launch_row3_t(fb_ctx *c, const RowArgs &a)
     const int npairs = a.nx / 2;
     int grid = (npairs + C::GP - 1) / C::GP;
     if (grid > c->max_wg) grid = c->max_wg;
-    const bool slab = a.m_sstride != 0 || a.t_sstride != 0;
+    const bool slab = c->world > 1;
     auto kern = slab ? k_row3<M, MODE, true> : k_row3<M, MODE, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, c->stream, a, (const cf *)c->d_tw_row3);
     HIPCHK(hipGetLastError());
@@ -462,12 +502,9 @@ static int launch_row8(fb_ctx *c, const RowArgs &a)
     int grid = npairs, cap = c->max_wg / 4;   // two resident workgroups per CU, each loops over row pairs
     if (const char *e = getenv("FB_ROW_GRID")) { int v = atoi(e); if (v >= 64) cap = v; }
     if (grid > cap) grid = cap;
-    auto kern = k_row8<false>;                // slab-blocked exchange buffers keep the Stockham kernel (launch_row)
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Row8::LDS_BYTES));
-        attr_set = true;
-    }
+    auto kern = c->world > 1 ? k_row8<true> : k_row8<false>;
+    int rc = set_max_lds(c, (const void *)kern, Row8::LDS_BYTES);
+    if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Row8::LDS_BYTES, c->stream, a, (const cf *)c->d_tw_row3);
     HIPCHK(hipGetLastError());
     return FB_OK;
@@ -475,7 +512,8 @@ static int launch_row8(fb_ctx *c, const RowArgs &a)
 
 template <int MODE> static int launch_row(fb_ctx *c, const RowArgs &a)
 {
-    if (MODE == ROW_FUSED && c->use_row8 && a.nx >= 2 && a.m_sstride == 0 && a.t_sstride == 0) return launch_row8(c, a);
+    if (a.nx <= 0) return FB_OK;
+    if (MODE == ROW_FUSED && c->use_row8 && a.nx >= 2) return launch_row8(c, a);
     switch (c->ny) {
     case 192: return launch_row3_t<64, MODE>(c, a);
     case 384: return launch_row3_t<128, MODE>(c, a);
@@ -502,23 +540,25 @@ static int col_grid(const fb_ctx *c, long ntiles)
     return (int)(g ? g : 1);
 }
 
-// natural rows (one block) or, for the 4-field exchange buffer of a slab model, [dst][field][XL][KS]
+// natural rows (one block) or, for the 4-field exchange buffer of a slab model, [dst][field][XL][ncols]
 static RowMap rowmap_natural() { RowMap r; r.xl_shift = 31; r.xl_mask = 0x7fffffff; r.dstride = 0; r.xl = 0; return r; }
 static int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
-static RowMap rowmap_w4(const fb_ctx *c)
+static RowMap rowmap_w4(const fb_ctx *c, const ColGroup &G)
 {
     if (c->world == 1) return rowmap_natural();
-    RowMap r; r.xl_shift = ilog2(c->XL); r.xl_mask = c->XL - 1; r.dstride = 4L * c->XL * c->P;
+    RowMap r; r.xl_shift = ilog2(c->XL); r.xl_mask = c->XL - 1; r.dstride = 4L * c->XL * G.ncols;
     r.xl = is_pow2(c->XL) ? 0 : c->XL;
     return r;
 }
-static long w4_fstride(const fb_ctx *c) { return c->world == 1 ? (long)c->nx * c->P : (long)c->XL * c->P; }
+static size_t grp_elems(const fb_ctx *c, const ColGroup &G) { return (size_t)c->nx * G.ncols; }
+static long w4_fstride(const fb_ctx *c, const ColGroup &G) { return c->world == 1 ? (long)grp_elems(c, G) : (long)c->XL * G.ncols; }
 
-template <int DIR> static int launch_col_strided(fb_ctx *c, cf *data, int nfields, long fstride, RowMap rm = rowmap_natural(), int ct0 = 0, int nct = -1)
+template <int DIR> static int launch_col_strided(fb_ctx *c, const ColGroup &G, cf *data, int nfields, long fstride, RowMap rm = rowmap_natural(),
+                                                 int ct0 = 0, int nct = -1)
 {
-    if (nct < 0) nct = c->P / 16 - ct0;
-    if (nct == 0) return FB_OK;
-    ColArgs a; a.data = data; a.fstride = fstride; a.rm = rm; a.ct0 = ct0; a.nct = nct; a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
+    if (nct < 0) nct = G.ncols / 16 - ct0;
+    if (nct <= 0) return FB_OK;
+    ColArgs a; a.data = data; a.fstride = fstride; a.rm = rm; a.ct0 = ct0; a.nct = nct; a.nfields = nfields; a.P = G.ncols; a.N1 = c->N1; a.N2 = c->N2;
     a.pace = c->pace_strided;
     a.tw_n = c->d_tw_n1; a.tw_big = c->d_tw_big;
     const long ntiles = (long)nfields * c->N2 * nct;
@@ -536,12 +576,13 @@ template <int DIR> static int launch_col_strided(fb_ctx *c, cf *data, int nfield
     return FB_OK;
 }
 
-template <int DIR> static int launch_col_block(fb_ctx *c, cf *data, int nfields, long fstride)
+template <int DIR> static int launch_col_block(fb_ctx *c, const ColGroup &G, cf *data, int nfields, long fstride)
 {
-    ColArgs a; a.data = data; a.fstride = fstride; a.rm = rowmap_natural(); a.ct0 = 0; a.nct = c->P / 16; a.nfields = nfields; a.P = c->P; a.N1 = c->N1; a.N2 = c->N2;
+    if (G.ncols == 0) return FB_OK;
+    ColArgs a; a.data = data; a.fstride = fstride; a.rm = rowmap_natural(); a.ct0 = 0; a.nct = G.ncols / 16; a.nfields = nfields; a.P = G.ncols; a.N1 = c->N1; a.N2 = c->N2;
     a.pace = 0;
     a.tw_n = c->d_tw_n2; a.tw_big = c->d_tw_big;
-    const long ntiles = (long)nfields * c->N1 * (c->P / 16);
+    const long ntiles = (long)nfields * c->N1 * (G.ncols / 16);
     const dim3 g(col_grid(c, ntiles)), b(256);
     switch (c->N2) {
     case 8: hipLaunchKernelGGL((k_col_block<8, DIR>), g, b, 0, c->stream, a); break;
@@ -557,7 +598,7 @@ template <int DIR> static int launch_col_block(fb_ctx *c, cf *data, int nfields,
 
 static int launch_col_mid(fb_ctx *c, const MidArgs &a)
 {
-    if (a.nct == 0) return FB_OK;
+    if (a.nct <= 0) return FB_OK;
     const long ntiles = (long)c->N1 * a.nct;
     const dim3 g(col_grid(c, ntiles)), b(256);
     switch (c->N2) {
@@ -572,7 +613,20 @@ static int launch_col_mid(fb_ctx *c, const MidArgs &a)
     return FB_OK;
 }
 
-static size_t priv_elems(const fb_ctx *c) { return (size_t)c->nx * c->P; }
+static size_t priv_elems(const fb_ctx *c) { return grp_elems(c, c->grp[0]); }   // one GPU: the one group
+
+// tiles of every group that hold at least one column inside the dealiasing circle (the rest is frozen forever)
+static void finish_groups(fb_ctx *c)
+{
+    int jmax = 0;                                          // first ky with ky^2 >= gws (fftwfop.cpp:57-61)
+    while (jmax < c->hy && (double)jmax * (double)jmax < c->gws) ++jmax;
+    for (int g = 0; g < c->ngroups; ++g) {
+        ColGroup &G = c->grp[g];
+        const int act = (jmax - G.ky0 + 15) / 16;
+        G.nct_active = act < 0 ? 0 : (act > G.ncols / 16 ? G.ncols / 16 : act);
+        if (getenv("FB_NO_COLUMN_SKIP")) G.nct_active = G.ncols / 16;
+    }
+}
 
 // The strided x sub-pass reads rows N2*P*8 bytes apart; how well that stride spreads over the HBM channels
 // depends on the pitch in a way that is specific to the memory controller's address hash (measured on MI355X,
@@ -581,6 +635,7 @@ static size_t priv_elems(const fb_ctx *c) { return (size_t)c->nx * c->P; }
 // Results do not depend on the pitch (pad columns are zero and every pass is linear).
 static int autotune_pitch(fb_ctx *c)
 {
+    finish_groups(c);
     if (c->world != 1 || getenv("FB_PITCH_EXTRA") || getenv("FB_NO_PITCH_TUNE")) return FB_OK;
     if ((size_t)c->nx * c->P * sizeof(cf) < ((size_t)32 << 20)) return FB_OK;      // cache-resident grids: nothing to gain
     const int P0 = c->P, NC = 4;
@@ -591,19 +646,20 @@ static int autotune_pitch(fb_ctx *c)
     hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f; int bestP = P0;
     for (int k = 0; k < NC; ++k) {
-        c->P = P0 + 16 * k;
+        ColGroup G = c->grp[0]; G.ncols = P0 + 16 * k;
         float tmin = 1e30f;
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0, c->stream);
-            int rc = launch_col_strided<+1>(c, buf, 1, 0);
+            int rc = launch_col_strided<+1>(c, G, buf, 1, 0);
             hipEventRecord(e1, c->stream);
             hipEventSynchronize(e1);
             float ms = 0.f;
             if (rc == FB_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0 && ms < tmin) tmin = ms;
         }
-        if (tmin < best * 0.97f) { best = tmin; bestP = c->P; }     // a larger pitch must win by 3 % to be taken
+        if (tmin < best * 0.97f) { best = tmin; bestP = G.ncols; }     // a larger pitch must win by 3 % to be taken
     }
-    c->P = bestP;
+    c->P = c->KA = c->katot = c->grp[0].ncols = bestP;
+    finish_groups(c);
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(buf);
     return FB_OK;
@@ -618,42 +674,62 @@ static int ensure_scratch(fb_ctx *c)
     return FB_OK;
 }
 
+// ---- row-pass views (fb_kernels.h: RowView) ----
+static unsigned magic_div(int d) { return d > 0 ? (unsigned)((1ull << 32) / (unsigned)d) + 1u : 0u; }
+// one GPU: nfields arrays of pitch P, fstride apart
+static RowView view_single(const fb_ctx *c, const cf *base, long fstride)
+{
+    RowView v; memset(&v, 0, sizeof(v));
+    v.a = v.f = base; v.fstrA = v.fstrF = fstride; v.ka = c->P; v.kf = 16; v.katot = 0x7fffffff;
+    return v;
+}
+// multi-GPU exchange buffers [peer][nfields][XL][KA] (active columns) and [peer][nfields][XL][KF] (frozen columns)
+static RowView view_slab(const fb_ctx *c, const cf *act, const cf *frz, int nfields)
+{
+    RowView v; memset(&v, 0, sizeof(v));
+    v.a = act; v.f = frz ? frz : act; v.ka = c->KA; v.kf = c->KF > 0 ? c->KF : 16; v.katot = c->katot;
+    v.fstrA = (long)c->XL * v.ka; v.fstrF = (long)c->XL * v.kf;
+    v.sstrA = (long)nfields * v.fstrA; v.sstrF = (long)nfields * v.fstrF;
+    v.magA = magic_div(v.ka); v.magF = magic_div(v.kf);
+    return v;
+}
+
 static RowArgs row_args_base(const fb_ctx *c)
 {
     RowArgs a; memset(&a, 0, sizeof(a));
-    const long ss = c->world > 1 ? (long)c->XL * c->P : 0;       // slab stride of the transpose buffers
-    a.ks = c->P; a.m_sstride = ss; a.t_sstride = ss; a.nx = c->XL; a.tw_bwd = c->d_tw_row_bwd; a.tw_fwd = c->d_tw_row_fwd;
+    a.x0 = 0; a.nx = c->XL; a.tw_bwd = c->d_tw_row_bwd; a.tw_fwd = c->d_tw_row_fwd; a.t_frozen = 1;
     return a;
 }
 
-// real [nx][ny] -> private spectral layout (dst: nx*P complex, pad columns must be zero-initialised)
+// real [nx][ny] -> private spectral layout (dst: nx*P complex, pad columns must be zero-initialised)      [one GPU]
 static int r2c_private(fb_ctx *c, const float *d_real, cf *dst)
 {
-    RowArgs a = row_args_base(c); a.rin = d_real; a.T = dst;
+    RowArgs a = row_args_base(c); a.rin = d_real; a.T = view_single(c, dst, 0);
     int rc;
     if ((rc = launch_row<ROW_FWD>(c, a))) return rc;
-    if ((rc = launch_col_strided<-1>(c, dst, 1, 0))) return rc;
-    return launch_col_block<-1>(c, dst, 1, 0);
+    if ((rc = launch_col_strided<-1>(c, c->grp[0], dst, 1, 0))) return rc;
+    return launch_col_block<-1>(c, c->grp[0], dst, 1, 0);
 }
 
-// private spectral layout (work: destroyed) -> real [nx][ny] * scale
+// private spectral layout (work: destroyed) -> real [nx][ny] * scale                                       [one GPU]
 static int c2r_private(fb_ctx *c, cf *work, float *d_real, float scale)
 {
     int rc;
-    if ((rc = launch_col_block<+1>(c, work, 1, 0))) return rc;
-    if ((rc = launch_col_strided<+1>(c, work, 1, 0))) return rc;
-    RowArgs a = row_args_base(c); a.M = work; a.rout = d_real; a.scale = scale;
+    if ((rc = launch_col_block<+1>(c, c->grp[0], work, 1, 0))) return rc;
+    if ((rc = launch_col_strided<+1>(c, c->grp[0], work, 1, 0))) return rc;
+    RowArgs a = row_args_base(c); a.M = view_single(c, work, 0); a.rout = d_real; a.scale = scale;
     return launch_row<ROW_INV>(c, a);
 }
 
 // 3-pass row layout <-> the tile-major layout of the state arrays (out-of-place)
 static bool state_tm(const fb_ctx *c) { return c->N2 >= 32; }
-static int state_convert(fb_ctx *c, const cf *in, cf *out, bool to_tm)
+static int state_convert(fb_ctx *c, const ColGroup &G, const cf *in, cf *out, bool to_tm)
 {
-    if (!state_tm(c)) { HIPCHK(hipMemcpyAsync(out, in, priv_elems(c) * sizeof(cf), hipMemcpyDeviceToDevice, c->stream)); return FB_OK; }
-    const size_t total = priv_elems(c);
-    if (to_tm) hipLaunchKernelGGL((k_state_relayout<true>), dim3(grid_for(c, total)), dim3(256), 0, c->stream, in, out, c->nx, c->P, c->N2);
-    else hipLaunchKernelGGL((k_state_relayout<false>), dim3(grid_for(c, total)), dim3(256), 0, c->stream, in, out, c->nx, c->P, c->N2);
+    if (G.ncols == 0) return FB_OK;
+    if (!state_tm(c)) { HIPCHK(hipMemcpyAsync(out, in, grp_elems(c, G) * sizeof(cf), hipMemcpyDeviceToDevice, c->stream)); return FB_OK; }
+    const size_t total = grp_elems(c, G);
+    if (to_tm) hipLaunchKernelGGL((k_state_relayout<true>), dim3(grid_for(c, total)), dim3(256), 0, c->stream, in, out, c->nx, G.ncols, c->N2);
+    else hipLaunchKernelGGL((k_state_relayout<false>), dim3(grid_for(c, total)), dim3(256), 0, c->stream, in, out, c->nx, G.ncols, c->N2);
     HIPCHK(hipGetLastError());
     return FB_OK;
 }
@@ -692,14 +768,19 @@ extern "C" int fb_c2r(fb_ctx *c, const float *d_in, float *d_out, int normalize)
 // --------------------------------------------------------------------------------------------
 // fused RK4 model
 // --------------------------------------------------------------------------------------------
+// per column group: state arrays in the private layouts (nx*ncols complex each) and the exchange buffers.
+// One GPU: w4_recv == w4_send (4 fields) and t_recv == t_send (no exchange).  Multi-GPU (engine-owned):
+//   w4_send [dst][4][XL][ncols]  destination-blocked, written by the column kernels     -> all-to-all ->
+//   w4_recv [src][4][XL][ncols]  block s = rank s's ky slab of this rank's rows, read by the row pass
+//   t_send  [dst][XL][ncols]     written by the row pass                                -> all-to-all ->
+//   t_recv  [nx][ncols]          block s = rows of rank s, read by the column kernels
+struct GroupBufs { cf *ZA, *ZB, *ACC, *w4_send, *w4_recv, *t_send, *t_recv; };
+
 struct fb_model {
     fb_ctx *c;
     float nu, dt;
-    cf *ZA, *ZB, *ACC, *TT, *W4;    // private layouts, nx*P complex each (W4: 4 of them)
-    // slab mode: the four transpose buffers are the caller's (torch tensors handed to RCCL);
-    // world == 1: w4_recv == w4_send == W4 and t_send == t_recv == TT (no exchange)
-    cf *w4_send, *w4_recv, *t_send, *t_recv;
-    bool own_buffers;
+    GroupBufs gb[2];
+    bool phase_flow;                 // driven phase by phase (fb_slab_*): always the three-kernel column path
     // single-pass x-transform path (fb_col_full.h): ZA/ZB/ACC then use that kernel's private layout and
     // the frozen ky = ny/2 column of vort_c is kept in znyq[nx] (natural kx order)
     bool full;
@@ -709,79 +790,55 @@ struct fb_model {
     bool use_graph, warmed;
     hipGraphExec_t graph_exec;
     const float *graph_src; hipStream_t graph_stream;
-    float *src;                      // vort_src or NULL (== zeros)
+    float *src;                      // vort_src (this rank's rows) or NULL (== zeros)
     cf *nat[3];                      // natural-layout temporaries for the record path (lazy)
-    // 0: derivative fields stale; 1: W4 holds the derivatives with the backward x pass finished on the frozen
-    // tiles only (phase flow: FB_PH_COL_BWD comes next); 2: finished on every tile (ready for the row pass)
+    // 0: derivative fields stale; 1: w4_send holds the derivatives with the backward x pass finished on the frozen
+    // tiles only (the backward strided pass on the active tiles comes next); 2: finished on every tile (ready for the row pass)
     int primed;
 };
 
-static int model_create_impl(fb_model **out, fb_ctx *c, float nu, float dt, bool own)
+static int model_create_impl(fb_model **out, fb_ctx *c, float nu, float dt, bool phase_flow)
 {
     if (!out || !c) return fail(FB_EINVAL, "fb_model_create: NULL");
     *out = nullptr;
     fb_model *m = new fb_model();
     memset(m, 0, sizeof(*m));
-    m->c = c; m->nu = nu; m->dt = dt; m->own_buffers = own;
+    m->c = c; m->nu = nu; m->dt = dt; m->phase_flow = phase_flow;
     // single-pass x transform (fb_col_full.h) where it applies: one GPU, nx = 4096, frozen Nyquist column, whole
     // 8-column tiles.  0.177 ms per stage against 0.21 ms for the three column kernels; FB_FULL_PASS=0 keeps the latter.
     const char *fp = getenv("FB_FULL_PASS");
-    m->full = own && c->world == 1 && c->nx == 4096 && c->nyq_frozen && ((c->ny / 2) % 8) == 0 && !(fp && fp[0] == '0');
+    m->full = !phase_flow && c->world == 1 && c->nx == 4096 && c->nyq_frozen && ((c->ny / 2) % 8) == 0 && !(fp && fp[0] == '0');
+    int rc = FB_OK;
+    auto alloc0 = [&](cf **p, size_t elems) {              // zero-initialised device array (pad columns stay zero: every pass is linear)
+        if (rc || elems == 0) return;
+        if (hipMalloc((void **)p, elems * sizeof(cf)) != hipSuccess) { rc = fail(FB_ENOMEM, "model allocation failed"); return; }
+        if (hipMemsetAsync(*p, 0, elems * sizeof(cf), c->stream) != hipSuccess) rc = fail(FB_EHIP, "hipMemsetAsync failed");
+    };
     if (m->full) {
-        if (hipMalloc((void **)&m->znyq, (size_t)c->nx * sizeof(cf)) != hipSuccess) { delete m; return fail(FB_ENOMEM, "model allocation failed"); }
-        static bool attr = false;
-        if (!attr) {
-            HIPCHK(hipFuncSetAttribute((const void *)k_col_full<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS_BYTES));
-            HIPCHK(hipFuncSetAttribute((const void *)k_col_full<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS_BYTES));
-            HIPCHK(hipFuncSetAttribute((const void *)k_col_full<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS_BYTES));
-            HIPCHK(hipFuncSetAttribute((const void *)k_col_full<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS_BYTES));
-            attr = true;
+        alloc0(&m->znyq, (size_t)c->nx);
+        for (int st = 0; st < 4 && !rc; ++st) {
+            const void *fn = st == 0 ? (const void *)k_col_full<0> : st == 1 ? (const void *)k_col_full<1> : st == 2 ? (const void *)k_col_full<2> : (const void *)k_col_full<3>;
+            rc = set_max_lds(c, fn, CF_LDS_BYTES);
         }
     }
-    const size_t n = priv_elems(c) * sizeof(cf);
-    cf **arr[] = {&m->ZA, &m->ZB, &m->ACC};
-    for (auto p : arr) {
-        if (hipMalloc((void **)p, n) != hipSuccess) { fb_model_destroy(m); return fail(FB_ENOMEM, "model allocation failed"); }
-        hipMemsetAsync(*p, 0, n, c->stream);
+    for (int g = 0; g < c->ngroups; ++g) {
+        const size_t n = grp_elems(c, c->grp[g]);
+        GroupBufs &B = m->gb[g];
+        alloc0(&B.ZA, n);
+        if (g == 0) { alloc0(&B.ZB, n); alloc0(&B.ACC, n); }     // the frozen group's state never changes: vort_c only
+        alloc0(&B.w4_send, 4 * n); alloc0(&B.t_send, n);
+        if (c->world > 1) { alloc0(&B.w4_recv, 4 * n); alloc0(&B.t_recv, n); }
+        else { B.w4_recv = B.w4_send; B.t_recv = B.t_send; }
     }
-    if (own) {
-        if (hipMalloc((void **)&m->TT, n) != hipSuccess || hipMalloc((void **)&m->W4, 4 * n) != hipSuccess) {
-            fb_model_destroy(m); return fail(FB_ENOMEM, "model allocation failed");
-        }
-        hipMemsetAsync(m->TT, 0, n, c->stream);
-        hipMemsetAsync(m->W4, 0, 4 * n, c->stream);
-        m->w4_send = m->w4_recv = m->W4; m->t_send = m->t_recv = m->TT;
-    }
+    if (rc) { fb_model_destroy(m); return rc; }
     *out = m;
     return FB_OK;
 }
 
 extern "C" int fb_model_create(fb_model **out, fb_ctx *c, float nu, float dt)
 {
-    if (c && c->world != 1) return fail(FB_EINVAL, "fb_model_create on a slab context: use fb_model_create_slab");
-    return model_create_impl(out, c, nu, dt, true);
-}
-
-extern "C" int fb_model_create_slab(fb_model **out, fb_ctx *c, float nu, float dt, float *d_w4_send, float *d_w4_recv,
-                                    float *d_t_send, float *d_t_recv)
-{
-    if (!d_w4_send || !d_w4_recv || !d_t_send || !d_t_recv) return fail(FB_EINVAL, "fb_model_create_slab: NULL buffer");
-    int rc = model_create_impl(out, c, nu, dt, false);
-    if (rc) return rc;
-    fb_model *m = *out;
-    m->w4_send = (cf *)d_w4_send; m->w4_recv = (cf *)d_w4_recv; m->t_send = (cf *)d_t_send; m->t_recv = (cf *)d_t_recv;
-    m->W4 = m->w4_send; m->TT = m->t_recv;
-    return FB_OK;
-}
-
-extern "C" int fb_slab_geometry(fb_ctx *c, int *rows_local, int *cols_per_slab, int *ky0, size_t *elems_per_field)
-{
-    if (!c) return fail(FB_EINVAL, "ctx NULL");
-    if (rows_local) *rows_local = c->XL;
-    if (cols_per_slab) *cols_per_slab = c->P;
-    if (ky0) *ky0 = c->ky0;
-    if (elems_per_field) *elems_per_field = priv_elems(c);
-    return FB_OK;
+    if (c && c->world != 1) return fail(FB_EINVAL, "fb_model_create on a slab context: use fb_slab_create");
+    return model_create_impl(out, c, nu, dt, false);
 }
 
 static void model_drop_graph(fb_model *m);
@@ -789,10 +846,14 @@ static void model_drop_graph(fb_model *m);
 extern "C" int fb_model_destroy(fb_model *m)
 {
     if (!m) return FB_OK;
-    hipFree(m->ZA); hipFree(m->ZB); hipFree(m->ACC);
+    for (GroupBufs &B : m->gb) {
+        if (B.w4_recv && B.w4_recv != B.w4_send) hipFree(B.w4_recv);
+        if (B.t_recv && B.t_recv != B.t_send) hipFree(B.t_recv);
+        cf *arr[] = {B.ZA, B.ZB, B.ACC, B.w4_send, B.t_send};
+        for (cf *p : arr) if (p) hipFree(p);
+    }
     if (m->znyq) hipFree(m->znyq);
     model_drop_graph(m);
-    if (m->own_buffers) { hipFree(m->TT); hipFree(m->W4); }
     if (m->src) hipFree(m->src);
     for (auto p : m->nat) if (p) hipFree(p);
     delete m;
@@ -803,12 +864,16 @@ extern "C" int fb_model_info(fb_model *m, size_t *hbm, size_t *alg)
 {
     if (!m) return fail(FB_EINVAL, "model NULL");
     const fb_ctx *c = m->c;
-    if (hbm) *hbm = 8 * priv_elems(c) * sizeof(cf) + (m->src ? (size_t)c->nx * c->ny * 4 : 0);
+    if (hbm) {
+        size_t n = m->src ? (size_t)c->XL * c->ny * 4 : 0;
+        for (int g = 0; g < c->ngroups; ++g) n += (c->world > 1 ? (g == 0 ? 13 : 11) : 8) * grp_elems(c, c->grp[g]) * sizeof(cf);
+        *hbm = n;
+    }
     if (alg) *alg = (size_t)320 * c->nx * c->ny;
     return FB_OK;
 }
 
-static MidArgs mid_args(fb_model *m, int stage);
+static MidArgs mid_args(fb_model *m, int g, int stage);
 static int full_import_state(fb_model *m, cf *spec3);
 static int full_export_state(fb_model *m, cf *dst);
 
@@ -818,13 +883,13 @@ extern "C" int fb_model_set_vort(fb_model *m, const float *d_vort)
     fb_ctx *c = m->c;
     NEED_SINGLE(c);
     m->warmed = false;                                      // the next fb_model_step starts with an eager (priming) step
-    cf *dst = m->ZB;                                        // 3-pass row layout in ZB (stage scratch), then into ZA's layout
+    cf *dst = m->gb[0].ZB;                                  // 3-pass row layout in ZB (stage scratch), then into ZA's layout
     HIPCHK(hipMemsetAsync(dst, 0, priv_elems(c) * sizeof(cf), c->stream));
     m->primed = 0;
     int rc = r2c_private(c, d_vort, dst);                   // main.cpp:256
     if (rc) return rc;
     if (m->full) return full_import_state(m, dst);
-    return state_convert(c, dst, m->ZA, true);
+    return state_convert(c, c->grp[0], dst, m->gb[0].ZA, true);
 }
 
 extern "C" int fb_model_set_source(fb_model *m, const float *d_src)
@@ -838,13 +903,15 @@ extern "C" int fb_model_set_source(fb_model *m, const float *d_src)
     return FB_OK;
 }
 
-static MidArgs mid_args(fb_model *m, int stage)
+static MidArgs mid_args(fb_model *m, int g, int stage)
 {
     fb_ctx *c = m->c;
+    const ColGroup &G = c->grp[g];
+    const GroupBufs &B = m->gb[g];
     MidArgs a;
-    a.Tin = m->t_recv; a.Zbase = m->ZA; a.Zcur = m->ZB; a.Acc = m->ACC; a.Zout = m->ZA; a.W4 = m->w4_send;
-    a.ct0 = 0; a.nct = stage < 0 ? c->P / 16 : c->nct_active;     // priming covers every column once
-    a.fstride = w4_fstride(c); a.rm = rowmap_w4(c); a.P = c->P; a.N1 = c->N1; a.N2 = c->N2; a.ky0 = c->ky0; a.stage = stage;
+    a.Tin = B.t_recv; a.Zbase = B.ZA; a.Zcur = B.ZB; a.Acc = B.ACC; a.Zout = B.ZA; a.W4 = B.w4_send;
+    a.ct0 = 0; a.nct = stage < 0 ? G.ncols / 16 : G.nct_active;     // priming covers every column once
+    a.fstride = w4_fstride(c, G); a.rm = rowmap_w4(c, G); a.P = G.ncols; a.N1 = c->N1; a.N2 = c->N2; a.ky0 = G.ky0; a.stage = stage;
     a.nu = m->nu; a.dt = m->dt; a.coef = make_coef(c); a.tw_n = c->d_tw_n2; a.tw_big = c->d_tw_big;
     return a;
 }
@@ -865,15 +932,17 @@ __global__ void k_nyq_col(cf *arr, cf *znyq, int nx, int P, int N1, int N2, int 
 static int full_import_state(fb_model *m, cf *spec3)
 {
     fb_ctx *c = m->c;
+    const ColGroup &G = c->grp[0];
+    GroupBufs &B = m->gb[0];
     int rc;
-    MidArgs a = mid_args(m, -1);
-    if ((rc = state_convert(c, spec3, m->ACC, true))) return rc;     // ACC is free here: tile-major copy for the priming pass
-    a.Zbase = m->ACC;
+    MidArgs a = mid_args(m, 0, -1);
+    if ((rc = state_convert(c, G, spec3, B.ACC, true))) return rc;     // ACC is free here: tile-major copy for the priming pass
+    a.Zbase = B.ACC;
     if ((rc = launch_col_mid(c, a))) return rc;
-    if ((rc = launch_col_strided<+1>(c, m->W4, 4, (long)priv_elems(c)))) return rc;
+    if ((rc = launch_col_strided<+1>(c, G, B.w4_send, 4, (long)priv_elems(c)))) return rc;
     hipLaunchKernelGGL((k_nyq_col<true>), dim3((c->nx + 255) / 256), dim3(256), 0, c->stream, spec3, m->znyq, c->nx, c->P, c->N1, c->N2, c->ny / 2);
     const int ntiles = (c->ny / 2) / 8;
-    hipLaunchKernelGGL((k_full_relayout<true>), dim3(c->max_wg), dim3(256), 0, c->stream, (const cf *)spec3, m->ZA, c->P, c->N1, c->N2, ntiles);
+    hipLaunchKernelGGL((k_full_relayout<true>), dim3(c->max_wg), dim3(256), 0, c->stream, (const cf *)spec3, B.ZA, c->P, c->N1, c->N2, ntiles);
     HIPCHK(hipGetLastError());
     m->primed = 2;
     return FB_OK;
@@ -885,7 +954,7 @@ static int full_export_state(fb_model *m, cf *dst)
     fb_ctx *c = m->c;
     HIPCHK(hipMemsetAsync(dst, 0, priv_elems(c) * sizeof(cf), c->stream));
     const int ntiles = (c->ny / 2) / 8;
-    hipLaunchKernelGGL((k_full_relayout<false>), dim3(c->max_wg), dim3(256), 0, c->stream, (const cf *)m->ZA, dst, c->P, c->N1, c->N2, ntiles);
+    hipLaunchKernelGGL((k_full_relayout<false>), dim3(c->max_wg), dim3(256), 0, c->stream, (const cf *)m->gb[0].ZA, dst, c->P, c->N1, c->N2, ntiles);
     hipLaunchKernelGGL((k_nyq_col<false>), dim3((c->nx + 255) / 256), dim3(256), 0, c->stream, dst, m->znyq, c->nx, c->P, c->N1, c->N2, c->ny / 2);
     HIPCHK(hipGetLastError());
     return FB_OK;
@@ -894,10 +963,11 @@ static int full_export_state(fb_model *m, cf *dst)
 static int launch_col_full(fb_model *m, int stage)
 {
     fb_ctx *c = m->c;
+    const GroupBufs &B = m->gb[0];
     FullArgs a;
-    a.Tin = m->t_recv; a.Zbase = m->ZA; a.Zcur = m->ZB; a.Acc = m->ACC; a.Zout = m->ZA; a.W4 = m->w4_send;
+    a.Tin = B.t_recv; a.Zbase = B.ZA; a.Zcur = B.ZB; a.Acc = B.ACC; a.Zout = B.ZA; a.W4 = B.w4_send;
     a.fstride = (long)priv_elems(c); a.P = c->P; a.ntiles = (c->ny / 2) / 8; a.stage = stage; a.nu = m->nu; a.dt = m->dt;
-    a.ntiles_active = c->nct_active * 2 < a.ntiles ? c->nct_active * 2 : a.ntiles;
+    a.ntiles_active = c->grp[0].nct_active * 2 < a.ntiles ? c->grp[0].nct_active * 2 : a.ntiles;
     if (getenv("FB_FULL_NOSKIP")) a.ntiles_active = a.ntiles;
     a.coef = make_coef(c); a.tw256 = c->d_tw_256; a.tw4096 = c->d_tw_big;
     const dim3 g(a.ntiles), b(CF_THREADS);
@@ -911,22 +981,46 @@ static int launch_col_full(fb_model *m, int stage)
     return FB_OK;
 }
 
-// priming: derivatives of vort_c for every column; the frozen high-ky tiles get their backward strided
-// sub-pass here, once -- the per-stage passes only touch the active tiles
+// ---- the local passes of one RK stage, shared by the fused single-GPU flow and the multi-GPU driver ----------------
+// priming: derivatives of vort_c for every column of every group; the frozen tiles get their backward strided
+// sub-pass here, once -- the per-stage passes only touch the active tiles of group 0
 static int model_prime(fb_model *m)
 {
     fb_ctx *c = m->c;
     int rc;
-    if ((rc = launch_col_mid(c, mid_args(m, -1)))) return rc;
+    for (int g = 0; g < c->ngroups; ++g) {
+        const ColGroup &G = c->grp[g];
+        if ((rc = launch_col_mid(c, mid_args(m, g, -1)))) return rc;
+        if ((rc = launch_col_strided<+1>(c, G, m->gb[g].w4_send, 4, w4_fstride(c, G), rowmap_w4(c, G), G.nct_active, G.ncols / 16 - G.nct_active))) return rc;
+    }
     m->primed = 1;
-    return launch_col_strided<+1>(c, m->w4_send, 4, w4_fstride(c), rowmap_w4(c), c->nct_active, c->P / 16 - c->nct_active);
+    return FB_OK;
 }
-// backward strided sub-pass on the active tiles: the phase flow's FB_PH_COL_BWD, or the fused flow's
-// catch-up right after priming (its stage loop starts with the row pass)
-static int model_col_bwd_active(fb_model *m)
+// backward strided sub-pass on the active tiles, fields [f0, f1): the multi-GPU step pipelines it field by field against
+// the exchange; the fused flow runs it once right after priming (its stage loop starts with the row pass)
+static int model_col_bwd_active(fb_model *m, int f0 = 0, int f1 = 4)
 {
     fb_ctx *c = m->c;
-    return launch_col_strided<+1>(c, m->w4_send, 4, w4_fstride(c), rowmap_w4(c), 0, c->nct_active);
+    const ColGroup &G = c->grp[0];
+    return launch_col_strided<+1>(c, G, m->gb[0].w4_send + (size_t)f0 * w4_fstride(c, G), f1 - f0, w4_fstride(c, G), rowmap_w4(c, G), 0, G.nct_active);
+}
+static RowArgs fused_row_args(fb_model *m, int x0, int nrows)
+{
+    fb_ctx *c = m->c;
+    RowArgs a = row_args_base(c);
+    if (c->world == 1) { a.M = view_single(c, m->gb[0].w4_recv, (long)priv_elems(c)); a.T = view_single(c, m->gb[0].t_send, 0); }
+    else { a.M = view_slab(c, m->gb[0].w4_recv, m->gb[1].w4_recv, 4); a.T = view_slab(c, m->gb[0].t_send, m->gb[1].t_send, 1); a.t_frozen = 0; }
+    a.src = m->src; a.scale = 1.0f / (float)((size_t)c->nx * c->ny); a.x0 = x0; a.nx = nrows;
+    return a;
+}
+// forward x pass of the tendency + RK stage update + derivatives of the new stage state (three-kernel path)
+static int model_col_fwd(fb_model *m, int stage)
+{
+    fb_ctx *c = m->c;
+    int rc;
+    if ((rc = launch_col_strided<-1>(c, c->grp[0], m->gb[0].t_recv, 1, 0, rowmap_natural(), 0, c->grp[0].nct_active))) return rc;
+    m->primed = 1;
+    return launch_col_mid(c, mid_args(m, 0, stage));
 }
 
 // optional per-launch HIP-event profiler (bench.py's roofline leg)
@@ -944,32 +1038,27 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
 {
     if (!m || nsteps < 0) return fail(FB_EINVAL, "fb_model_step: bad argument");
     fb_ctx *c = m->c;
-    if (c->world != 1) return fail(FB_EINVAL, "fb_model_step on a slab model: drive it with fb_model_phase + all-to-all");
+    if (c->world != 1 || m->phase_flow) return fail(FB_EINVAL, "fb_model_step on a slab model: drive it with fb_slab_step");
     int rc;
     if (nsteps == 0) return FB_OK;
     if (m->full && !m->primed) return fail(FB_EINVAL, "fb_model_step: set the state first");
     if (!m->primed && (rc = model_prime(m))) return rc;
     if (m->primed == 1 && !m->full) { if ((rc = model_col_bwd_active(m))) return rc; m->primed = 2; }
-    const float scale = 1.0f / (float)((size_t)c->nx * c->ny);
+    const ColGroup &G = c->grp[0];
+    GroupBufs &B = m->gb[0];
     for (int s = 0; s < nsteps; ++s) {
         for (int k = 0; k < 4; ++k) {
+            // row pass on the derivative fields left by the previous stage (or the priming pass) ...
+            const RowArgs a = fused_row_args(m, 0, c->XL);
+            PROF_BEGIN(1);
+            if ((rc = launch_row<ROW_FUSED>(c, a))) return rc;
+            PROF_END(1);
             if (m->full) {                        // two launches per stage: row pass, single-pass x transform
-                RowArgs a = row_args_base(c);
-                a.M = m->w4_recv; a.m_fstride = (long)priv_elems(c); a.T = m->t_send; a.src = m->src; a.scale = scale;
-                PROF_BEGIN(1);
-                if ((rc = launch_row<ROW_FUSED>(c, a))) return rc;
-                PROF_END(1);
                 PROF_BEGIN(3);
                 if ((rc = launch_col_full(m, k))) return rc;
                 PROF_END(3);
                 continue;
             }
-            // row pass on the derivative fields left by the previous stage (or the priming pass) ...
-            RowArgs a = row_args_base(c);
-            a.M = m->w4_recv; a.m_fstride = (long)priv_elems(c); a.T = m->t_send; a.src = m->src; a.scale = scale;
-            PROF_BEGIN(1);
-            if ((rc = launch_row<ROW_FUSED>(c, a))) return rc;
-            PROF_END(1);
             // ... then the x pass in column chunks, each chained forward -> update -> backward so that a
             // chunk's derivative fields are still in the Infinity Cache when the backward sub-pass reads them
             const int nchunk = c->col_chunks;
@@ -988,18 +1077,18 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
             }
             struct StreamGuard { fb_ctx *c; hipStream_t s; ~StreamGuard() { c->stream = s; } } guard{c, main_stream};
             for (int h = 0; h < nchunk; ++h) {
-                const int ct0 = (int)((long)c->nct_active * h / nchunk), ct1 = (int)((long)c->nct_active * (h + 1) / nchunk);
+                const int ct0 = (int)((long)G.nct_active * h / nchunk), ct1 = (int)((long)G.nct_active * (h + 1) / nchunk);
                 if (ct1 == ct0) continue;
                 c->stream = (nstr > 1 && h % nstr) ? c->aux[h % nstr - 1] : main_stream;
                 PROF_BEGIN(2);
-                if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0, rowmap_natural(), ct0, ct1 - ct0))) return rc;
+                if ((rc = launch_col_strided<-1>(c, G, B.t_recv, 1, 0, rowmap_natural(), ct0, ct1 - ct0))) return rc;
                 PROF_END(2);
-                MidArgs ma = mid_args(m, k); ma.ct0 = ct0; ma.nct = ct1 - ct0;
+                MidArgs ma = mid_args(m, 0, k); ma.ct0 = ct0; ma.nct = ct1 - ct0;
                 PROF_BEGIN(3);
                 if ((rc = launch_col_mid(c, ma))) return rc;
                 PROF_END(3);
                 PROF_BEGIN(0);
-                if ((rc = launch_col_strided<+1>(c, m->w4_send, 4, (long)priv_elems(c), rowmap_natural(), ct0, ct1 - ct0))) return rc;
+                if ((rc = launch_col_strided<+1>(c, G, B.w4_send, 4, (long)priv_elems(c), rowmap_natural(), ct0, ct1 - ct0))) return rc;
                 PROF_END(0);
             }
             c->stream = main_stream;
@@ -1052,57 +1141,6 @@ extern "C" int fb_model_step(fb_model *m, int nsteps)
     return FB_OK;
 }
 
-// One phase of the slab-decomposed step; the caller performs the all-to-all transposes between
-// phases (see include/fftbaro.h).  Valid for world == 1 too (then no exchange is needed).
-extern "C" int fb_model_phase(fb_model *m, int phase, int stage, const float *d_real_in, float *d_real_out)
-{
-    if (!m) return fail(FB_EINVAL, "model NULL");
-    fb_ctx *c = m->c;
-    const long E = (long)priv_elems(c);
-    const float scale = 1.0f / (float)((size_t)c->nx * c->ny);
-    int rc;
-    switch (phase) {
-    case FB_PH_PRIME:                                       // derivatives of vort_c -> w4_send (block sub-pass done)
-        return model_prime(m);
-    case FB_PH_COL_BWD:                                     // strided backward sub-pass on the 4 fields (in w4_send)
-        if (m->primed != 1) return fail(FB_EINVAL, "FB_PH_COL_BWD without FB_PH_PRIME / FB_PH_COL_FWD before it");
-        m->primed = 2;
-        return model_col_bwd_active(m);
-    case FB_PH_ROW: {                                       // w4_recv (row slabs) -> tendency rows in t_send
-        RowArgs a = row_args_base(c);
-        a.M = m->w4_recv; a.m_fstride = w4_fstride(c); a.T = m->t_send; a.src = m->src; a.scale = scale;
-        if (c->world > 1) a.m_sstride = 4L * c->XL * c->P;   // w4_recv: [src rank][field][XL][KS]
-        return launch_row<ROW_FUSED>(c, a);
-    }
-    case FB_PH_COL_FWD:                                     // t_recv (column slab) -> forward x pass + RK update + derivatives
-        if (stage < 0 || stage > 3) return fail(FB_EINVAL, "fb_model_phase: stage");
-        if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0, rowmap_natural(), 0, c->nct_active))) return rc;
-        m->primed = 1;
-        return launch_col_mid(c, mid_args(m, stage));
-    case FB_PH_R2C_ROWS: {                                  // local real rows -> y-transformed rows in t_send
-        if (!d_real_in) return fail(FB_EINVAL, "fb_model_phase: d_real_in NULL");
-        RowArgs a = row_args_base(c); a.rin = d_real_in; a.T = m->t_send;
-        return launch_row<ROW_FWD>(c, a);
-    }
-    case FB_PH_R2C_COLS:                                    // t_recv -> vort_c (private layout)
-        if ((rc = launch_col_strided<-1>(c, m->t_recv, 1, 0)) || (rc = launch_col_block<-1>(c, m->t_recv, 1, 0))) return rc;
-        m->primed = 0;
-        return state_convert(c, m->t_recv, m->ZA, true);
-    case FB_PH_C2R_COLS:                                    // copy of vort_c -> x-inverse-transformed columns in t_recv
-        // vort_c is staged in t_recv's buffer-sized scratch (field 0 region is destination-blocked in slab mode)
-        if ((rc = state_convert(c, m->ZA, m->t_recv, false))) return rc;
-        if ((rc = launch_col_block<+1>(c, m->t_recv, 1, 0))) return rc;
-        if ((rc = launch_col_strided<+1>(c, m->t_recv, 1, 0))) return rc;      // natural [x][KS] == [dst][XL][KS]
-        return FB_OK;
-    case FB_PH_C2R_ROWS: {                                  // t_send (row slabs [src][XL][KS]) -> normalised real rows
-        if (!d_real_out) return fail(FB_EINVAL, "fb_model_phase: d_real_out NULL");
-        RowArgs a = row_args_base(c); a.M = m->t_send; a.m_fstride = 0; a.rout = d_real_out; a.scale = scale;
-        return launch_row<ROW_INV>(c, a);
-    }
-    }
-    return fail(FB_EINVAL, "fb_model_phase: unknown phase");
-}
-
 extern "C" int fb_model_time_steps(fb_model *m, int nsteps, float *total_ms)
 {
     if (!m || !total_ms) return fail(FB_EINVAL, "fb_model_time_steps: NULL");
@@ -1140,13 +1178,10 @@ extern "C" int fb_model_get_spectrum(fb_model *m, float *d_spec)
 {
     if (!m || !d_spec) return fail(FB_EINVAL, "fb_model_get_spectrum: NULL");
     NEED_SINGLE(m->c);
-    if (m->full) {
-        int rc;
-        if ((rc = ensure_scratch(m->c)) || (rc = full_export_state(m, m->c->d_scratch))) return rc;
-        return relayout(m->c, m->c->d_scratch, (cf *)d_spec, false);
-    }
     int rc;
-    if ((rc = ensure_scratch(m->c)) || (rc = state_convert(m->c, m->ZA, m->c->d_scratch, false))) return rc;
+    if ((rc = ensure_scratch(m->c))) return rc;
+    if (m->full) { if ((rc = full_export_state(m, m->c->d_scratch))) return rc; }
+    else if ((rc = state_convert(m->c, m->c->grp[0], m->gb[0].ZA, m->c->d_scratch, false))) return rc;
     return relayout(m->c, m->c->d_scratch, (cf *)d_spec, false);
 }
 
@@ -1156,12 +1191,10 @@ extern "C" int fb_model_set_spectrum(fb_model *m, const float *d_spec)
     NEED_SINGLE(m->c);
     m->primed = 0;
     m->warmed = false;
-    if (m->full) {
-        int rc = relayout(m->c, (const cf *)d_spec, m->ZB, true);
-        return rc ? rc : full_import_state(m, m->ZB);
-    }
-    int rc = relayout(m->c, (const cf *)d_spec, m->ZB, true);
-    return rc ? rc : state_convert(m->c, m->ZB, m->ZA, true);
+    int rc = relayout(m->c, (const cf *)d_spec, m->gb[0].ZB, true);
+    if (rc) return rc;
+    if (m->full) return full_import_state(m, m->gb[0].ZB);
+    return state_convert(m->c, m->c->grp[0], m->gb[0].ZB, m->gb[0].ZA, true);
 }
 
 extern "C" int fb_model_get_vort(fb_model *m, float *d_vort)
@@ -1173,7 +1206,7 @@ extern "C" int fb_model_get_vort(fb_model *m, float *d_vort)
     if ((rc = ensure_scratch(c))) return rc;
     // copy of vort_c (main.cpp:273), c2r, normalise (main.cpp:275)
     if (m->full) { if ((rc = full_export_state(m, c->d_scratch))) return rc; }
-    else if ((rc = state_convert(c, m->ZA, c->d_scratch, false))) return rc;
+    else if ((rc = state_convert(c, c->grp[0], m->gb[0].ZA, c->d_scratch, false))) return rc;
     return c2r_private(c, c->d_scratch, d_vort, 1.0f / (float)((size_t)c->nx * c->ny));
 }
 
@@ -1198,5 +1231,7 @@ extern "C" int fb_model_get_diag(fb_model *m, float *d_psi, float *d_u, float *d
     }
     return FB_OK;
 }
+
+#include "fb_slab_driver.h"
 
 // field I/O (fb_write_field / fb_read_field, writeField / readField): fb_fieldio.cpp

@@ -1,30 +1,73 @@
 """Slab-decomposed RK4 stepping over the GPUs of one node.
 
-One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  Physical fields are
-split by x rows, spectral fields by ky columns; every 2-D transform needs one all-to-all
-transpose between its row pass and its column pass: per RK stage one transpose of the four
-derivative fields (columns -> rows) and one of the tendency (rows -> columns).  The local
-passes are the engine's HIP kernels behind `fb_model_phase` (include/fftbaro.h); this module
-owns the four exchange buffers and the collectives.  The reference has no counterpart (it is
-single-process); the decomposition reproduces main.cpp:286-317 exactly as the fused single-GPU
-path does.
+One process per GPU.  Physical fields are split by x rows, spectral fields by ky columns: the ACTIVE columns
+(ky < world*KA: every mode inside the dealiasing circle) evenly over the ranks, the FROZEN columns beyond them likewise
+(their modes are masked, fftwfop.cpp:57-61, and never change, SURVEY.md note N1).  Every 2-D transform needs one
+all-to-all transpose between its row pass and its column pass: per RK stage one of the four derivative fields
+(columns -> rows) and one of the tendency (rows -> columns), active columns only.  The reference has no counterpart (it
+is single-process); the decomposition computes exactly what main.cpp:286-317 computes.
 
-The compute backend is pluggable only so that the exchange logic can be exercised on CPU with
-`gloo` (tests/test_slab_cpu.py supplies a numpy backend built on the oracle); the product
-backend is `HipBackend` and there is no fallback to any other.
+Two drivers with one schedule:
+  * `EngineSlab` -- the product: the whole step (local HIP passes, exchange buffers, two streams, RCCL grouped
+    send/recv) lives behind the C ABI (`fb_slab_*`, csrc/fb_slab_driver.h); this class only bootstraps the transport
+    (RCCL unique id over torch.distributed; the in-process hub; a gloo callback for rehearsals on one GPU).
+  * `SlabModel(backend=...)` -- the same schedule spelled in Python over a pluggable compute backend, so that the
+    exchange logic (who sends which block to whom, in which order) runs on CPU under gloo with the numpy test double of
+    tests/slab_numpy_backend.py.  `stage_schedule()` is checked against the engine's `fb_slab_plan`.
+There is no fallback from one to the other.
 """
 import ctypes as C
+import math
 
 import numpy as np
 
-PH_PRIME, PH_COL_BWD, PH_ROW, PH_COL_FWD, PH_R2C_ROWS, PH_R2C_COLS, PH_C2R_COLS, PH_C2R_ROWS = range(8)
+OP_COL_BWD, OP_XCHG_W4, OP_ROW, OP_XCHG_T, OP_COL_FWD = 1, 2, 3, 4, 5
+
+
+def _round16(v):
+    return (v + 15) // 16 * 16
 
 
 def slab_geometry(nx, ny, world):
-    """(XL rows per rank, KS columns per slab) -- must match fb_create_slab (fftbaro.hip)."""
+    """(XL rows, KA active columns, KF frozen columns) per rank -- must match slab_split() in csrc/fftbaro.hip
+    (tests/test_slab_cpu.py compares with fb_slab_geometry)."""
     hy = ny // 2 + 1
-    ks = (hy + 16 * world - 1) // (16 * world) * 16
-    return nx // world, ks
+    dxw, dyw = math.ceil(float(np.float32(nx)) / 3.0), math.ceil(float(np.float32(ny)) / 3.0)
+    gws = float(np.float32(float(dxw) ** 2 + float(dyw) ** 2))                 # fftwfop.cpp:57
+    jmax = 0
+    while jmax < hy and float(jmax) * float(jmax) < gws:
+        jmax += 1
+    ka = _round16((jmax + world - 1) // world)
+    nf = hy - world * ka
+    kf = _round16((nf + world - 1) // world) if nf > 0 else 0
+    return nx // world, ka, kf
+
+
+def stage_plan(nx, ny, world):
+    """(field groups, row chunks) of one RK stage's two transposes -- mirrors slab_plan() in csrc/fb_slab_driver.h."""
+    xl, ka, _ = slab_geometry(nx, ny, world)
+    field_mb = xl * ka * 8.0 / (1 << 20)
+    fg = 1 if world == 1 else (4 if field_mb >= 2.0 else (2 if 2 * field_mb >= 2.0 else 1))
+    ch = 1 if world == 1 else (4 if field_mb >= 8.0 else (2 if field_mb >= 4.0 else 1))
+    while ch > 1 and ((xl // ch) & 1 or xl % ch):
+        ch >>= 1
+    return fg, ch
+
+
+def stage_schedule(nx, ny, world):
+    """Operations of one RK stage in issue order, as (kind, argument) -- mirrors fb_slab_plan."""
+    fg, ch = stage_plan(nx, ny, world)
+    ops = []
+    for g in range(fg):
+        ops.append((OP_COL_BWD, g))
+        if world > 1:
+            ops.append((OP_XCHG_W4, g))
+    for h in range(ch):
+        ops.append((OP_ROW, h))
+        if world > 1:
+            ops.append((OP_XCHG_T, h))
+    ops.append((OP_COL_FWD, 0))
+    return ops
 
 
 def local_rows(field, rank, world):
@@ -32,153 +75,251 @@ def local_rows(field, rank, world):
     return np.ascontiguousarray(field[rank * xl:(rank + 1) * xl])
 
 
-class HipBackend:
-    """Local passes on this rank's GPU through the C ABI."""
+# ---------------------------------------------------------------------------------------------------------------
+# the product driver: everything behind the C ABI
+# ---------------------------------------------------------------------------------------------------------------
+class _DevMem:
+    """A raw device allocation of the engine, viewed by torch through __cuda_array_interface__."""
 
-    def __init__(self, nx, ny, Lx, Ly, nu, dt, rank, world):
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = {"shape": (int(nfloats),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class EngineSlab:
+    """One rank of the engine-driven multi-GPU model (fb_slab_*).  transport:
+       "rccl"  -- ncclCommInitRank with an id that rank 0 creates and torch.distributed broadcasts (the product path)
+       "gloo"  -- torch.distributed point-to-point behind the callback transport (ranks may share one GPU: rehearsal)
+       hub     -- an integer handle from `local_hub(world)`: all ranks are threads of this process (rehearsal)
+       None    -- world == 1"""
+
+    def __init__(self, nx, ny=None, Lx=600000.0, Ly=600000.0, nu=6.5, dt=3.0, rank=0, world=1, transport=None, dist=None):
         import torch
         from . import binding as B
-        self.torch, self.B = torch, B
-        self.nx, self.ny, self.rank, self.world = nx, ny, rank, world
-        self.L = B.lib()
+        ny = ny or nx
+        self.torch, self.B, self.L = torch, B, B.lib()
+        self.nx, self.ny, self.rank, self.world, self.dist = nx, ny, rank, world, dist
         h = C.c_void_p()
-        B.check(self.L.fb_create_slab(C.byref(h), nx, ny, Lx, Ly, rank, world))
-        self.ctx = h
-        B.check(self.L.fb_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        xl, ks, ky0, e = C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
-        B.check(self.L.fb_slab_geometry(self.ctx, C.byref(xl), C.byref(ks), C.byref(ky0), C.byref(e)))
-        self.XL, self.KS, self.E = xl.value, ks.value, e.value
-        if world > 1:                               # one GPU: the engine may have autotuned a larger pitch
-            assert (self.XL, self.KS) == slab_geometry(nx, ny, world)
-        # exchange buffers as flat float32 (re,im interleaved): the dtype every RCCL collective takes
-        self.FL = 2 * self.E                    # tensor elements per field
-        z = lambda n: torch.zeros(n, dtype=torch.float32, device="cuda")
-        self.w4_send, self.w4_recv = z(4 * self.FL), z(4 * self.FL)
+        B.check(self.L.fb_slab_create(C.byref(h), nx, ny, Lx, Ly, nu, dt, rank, world))
+        self._h = h
+        v = [C.c_int() for _ in range(7)]
+        B.check(self.L.fb_slab_info(self._h, *[C.byref(x) for x in v]))
+        self.XL, self.KA, self.KF, self.kyA0, self.kyF0, self.field_groups, self.row_chunks = [x.value for x in v]
+        assert world == 1 or (self.XL, self.KA, self.KF) == slab_geometry(nx, ny, world)      # one rank: one group of all columns at the engine's pitch
+        self._cb = None
         if world > 1:
-            self.t_send, self.t_recv = z(self.FL), z(self.FL)
-        else:                                   # no exchange: the passes hand over in place
-            self.w4_recv = self.w4_send
-            self.t_send = self.t_recv = z(self.FL)
-        m = C.c_void_p()
-        B.check(self.L.fb_model_create_slab(C.byref(m), self.ctx, nu, dt, self.w4_send.data_ptr(), self.w4_recv.data_ptr(),
-                                            self.t_send.data_ptr(), self.t_recv.data_ptr()))
-        self.model = m
+            if transport == "rccl":
+                self._connect_rccl()
+            elif transport == "gloo":
+                self._connect_gloo()
+            elif isinstance(transport, int):
+                B.check(self.L.fb_slab_connect_local(self._h, C.c_void_p(transport)))
+            else:
+                raise B.FftBaroError("EngineSlab: world > 1 needs transport='rccl', 'gloo' or a local hub handle")
 
-    def phase(self, ph, stage=0, real_in=None, real_out=None):
-        self.B.check(self.L.fb_model_phase(self.model, ph, stage,
-                                           C.c_void_p(real_in.data_ptr()) if real_in is not None else None,
-                                           C.c_void_p(real_out.data_ptr()) if real_out is not None else None))
+    # -- transports
+    def _connect_rccl(self):
+        torch, dist = self.torch, self.dist
+        idbuf = C.create_string_buffer(128)
+        if self.rank == 0:
+            self.B.check(self.L.fb_slab_unique_id(idbuf))
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().tolist())
+        self.B.check(self.L.fb_slab_connect_rccl(self._h, C.create_string_buffer(raw, 128)))
 
-    def to_device_real(self, a):
-        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    def _connect_gloo(self):
+        torch, dist, world, rank = self.torch, self.dist, self.world, self.rank
 
-    def empty_real(self):
-        return self.torch.empty((self.XL, self.ny), dtype=self.torch.float32, device="cuda")
+        def alltoall(user, send, recv, stride, offset, count, stream):
+            try:
+                torch.cuda.synchronize()                                     # the engine's streams are not torch's
+                ops, keep = [], []
+                for p in range(world):
+                    s = torch.as_tensor(_DevMem(send + 4 * (p * stride + offset), count), device="cuda")
+                    r = torch.as_tensor(_DevMem(recv + 4 * (p * stride + offset), count), device="cuda")
+                    if p == rank:
+                        r.copy_(s)
+                    else:
+                        keep += [s, r]
+                        ops.append(dist.P2POp(dist.isend, s, p))
+                        ops.append(dist.P2POp(dist.irecv, r, p))
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+                torch.cuda.synchronize()
+                return 0
+            except Exception as e:                                            # never unwind through the C frame
+                import sys
+                print("slab gloo transport failed: %r" % (e,), file=sys.stderr)
+                return 1
+        self._cb = self.B.ALLTOALL_FN(alltoall)                               # keep the trampoline alive
+        self.B.check(self.L.fb_slab_connect_callback(self._h, self._cb, None))
 
-    def set_source(self, src_local):
-        if src_local is None:
-            self.B.check(self.L.fb_model_set_source(self.model, None))
+    # -- model surface (this rank's rows)
+    def _rows(self, a):
+        t = self.torch
+        if isinstance(a, np.ndarray):
+            a = t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+        assert a.is_cuda and a.dtype == t.float32 and a.is_contiguous() and tuple(a.shape) == (self.XL, self.ny)
+        return a
+
+    def set_vort_local(self, rows):
+        a = self._rows(rows)
+        self.B.check(self.L.fb_slab_set_vort_local(self._h, C.c_void_p(a.data_ptr())))
+        self.synchronize()
+
+    def set_source_local(self, rows):
+        if rows is None:
+            self.B.check(self.L.fb_slab_set_source_local(self._h, None))
         else:
-            t = self.to_device_real(src_local)
-            self.B.check(self.L.fb_model_set_source(self.model, C.c_void_p(t.data_ptr())))
-            self.torch.cuda.synchronize()
+            a = self._rows(rows)
+            self.B.check(self.L.fb_slab_set_source_local(self._h, C.c_void_p(a.data_ptr())))
+            self.synchronize()
+
+    def step(self, n=1):
+        self.B.check(self.L.fb_slab_step(self._h, n))
+
+    def vort_local(self):
+        out = self.torch.empty((self.XL, self.ny), dtype=self.torch.float32, device="cuda")
+        self.B.check(self.L.fb_slab_get_vort_local(self._h, C.c_void_p(out.data_ptr())))
+        self.synchronize()
+        return out
+
+    def time_steps(self, n):
+        ms = C.c_float()
+        self.B.check(self.L.fb_slab_time_steps(self._h, n, C.byref(ms)))
+        return ms.value
+
+    def synchronize(self):
+        self.B.check(self.L.fb_slab_synchronize(self._h))
 
     def close(self):
-        if getattr(self, "model", None):
-            self.L.fb_model_destroy(self.model)
-            self.L.fb_destroy(self.ctx)
-            self.model = None
+        if getattr(self, "_h", None):
+            self.L.fb_slab_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
-def _all_to_all(dist, out, inp, world):
-    """Equal-split all-to-all of contiguous 1-D tensors; RCCL's collective on GPUs, point-to-point
-    pairs elsewhere (gloo has no all_to_all)."""
-    if world == 1:
-        if out.data_ptr() != inp.data_ptr():
-            out.copy_(inp)
-        return
-    if dist.get_backend() == "nccl":
-        dist.all_to_all_single(out, inp)
-        return
+def local_hub(world):
+    """Handle of an in-process rendezvous for `world` EngineSlab ranks driven by `world` threads (one GPU)."""
+    from . import binding as B
+    h = C.c_void_p()
+    B.check(B.lib().fb_local_hub_create(C.byref(h), world))
+    return h.value
+
+
+def local_hub_destroy(hub):
+    from . import binding as B
+    B.lib().fb_local_hub_destroy(C.c_void_p(hub))
+
+
+def engine_plan(nx, ny, world):
+    """(field groups, row chunks, [(kind, argument), ...]) as the engine reports them (fb_slab_plan; no GPU needed)."""
+    from . import binding as B
+    fg, ch = C.c_int(), C.c_int()
+    ops = (C.c_int * 64)()
+    n = B.lib().fb_slab_plan(nx, ny, world, C.byref(fg), C.byref(ch), ops, 64)
+    return fg.value, ch.value, [(ops[i] // 16, ops[i] % 16) for i in range(n)]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the same schedule in Python over a pluggable compute backend (CPU rehearsal of the exchange logic)
+# ---------------------------------------------------------------------------------------------------------------
+def _all_to_all(dist, recv, send, world, stride, offset, count):
+    """Block (offset, count) of every peer's stride-sized slot: send[p*stride + offset ...] -> peer p's recv[me*stride + offset ...]."""
     rank = dist.get_rank()
-    n = inp.numel() // world
     ops = []
     for p in range(world):
+        s, r = send[p * stride + offset:p * stride + offset + count], recv[p * stride + offset:p * stride + offset + count]
         if p == rank:
-            out[p * n:(p + 1) * n].copy_(inp[p * n:(p + 1) * n])
+            r.copy_(s)
         else:
-            ops.append(dist.P2POp(dist.isend, inp[p * n:(p + 1) * n], p))
-            ops.append(dist.P2POp(dist.irecv, out[p * n:(p + 1) * n], p))
-    for r in dist.batch_isend_irecv(ops):
-        r.wait()
+            ops.append(dist.P2POp(dist.isend, s, p))
+            ops.append(dist.P2POp(dist.irecv, r, p))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
 
 
 class SlabModel:
-    """RK4 driver on `world` ranks.  API mirrors the single-GPU Model on the rank's local rows."""
+    """RK4 driver on `world` ranks, schedule in Python.  With backend=None this is the engine (EngineSlab)."""
 
-    def __init__(self, nx, ny=None, Lx=600000.0, Ly=600000.0, nu=6.5, dt=3.0, rank=0, world=1, backend=None, dist=None):
+    def __new__(cls, nx, ny=None, Lx=600000.0, Ly=600000.0, nu=6.5, dt=3.0, rank=0, world=1, backend=None, dist=None, transport=None):
+        if backend is None:                                   # the product: everything behind the C ABI
+            if dist is None and world > 1:
+                import torch.distributed as dist
+            if transport is None and world > 1:
+                transport = "rccl" if dist.get_backend() == "nccl" else "gloo"
+            return EngineSlab(nx, ny, Lx, Ly, nu, dt, rank, world, transport, dist)
+        return super().__new__(cls)
+
+    def __init__(self, nx, ny=None, Lx=600000.0, Ly=600000.0, nu=6.5, dt=3.0, rank=0, world=1, backend=None, dist=None, transport=None):
         ny = ny or nx
         self.nx, self.ny, self.rank, self.world = nx, ny, rank, world
         if dist is None and world > 1:
             import torch.distributed as dist
         self.dist = dist
-        self.be = backend if backend is not None else HipBackend(nx, ny, Lx, Ly, nu, dt, rank, world)
-        self.XL, self.KS, self.E = self.be.XL, self.be.KS, self.be.E
-        self.FL = getattr(self.be, "FL", self.be.E)      # tensor elements per field in the exchange buffers
+        self.be = backend
+        self.XL, self.KA, self.KF = slab_geometry(nx, ny, world)
+        assert (self.be.XL, self.be.KA, self.be.KF) == (self.XL, self.KA, self.KF)
+        self.field_groups, self.row_chunks = stage_plan(nx, ny, world)
         self.primed = False
 
-    # -- the two transposes -------------------------------------------------------------------
-    def _exchange_w4(self):
-        if self.world == 1:
-            return
-        # [dst][4][XL][KS] -> [src][4][XL][KS]: one collective for the four fields
-        _all_to_all(self.dist, self.be.w4_recv, self.be.w4_send, self.world)
+    def _xchg(self, recv, send, stride, offset, count):
+        if self.world > 1:
+            _all_to_all(self.dist, recv, send, self.world, stride, offset, count)
 
-    def _exchange_t(self, reverse=False):
-        if self.world == 1:
-            return
-        if reverse:                              # record path: columns (t_recv) -> rows (t_send)
-            _all_to_all(self.dist, self.be.t_send, self.be.t_recv, self.world)
-        else:
-            _all_to_all(self.dist, self.be.t_recv, self.be.t_send, self.world)
-
-    # -- state ------------------------------------------------------------------------------
+    # -- state
     def set_vort_local(self, vort_rows):
-        """vort_rows: this rank's [XL, ny] rows of the initial vorticity (main.cpp:143-144,256)."""
         be = self.be
         assert tuple(vort_rows.shape) == (self.XL, self.ny)
-        d = be.to_device_real(vort_rows)
-        be.phase(PH_R2C_ROWS, real_in=d)
-        self._exchange_t()
-        be.phase(PH_R2C_COLS)
+        be.r2c_rows(vort_rows)                                                    # -> t_send (active + frozen)
+        self._xchg(be.t_recv[0], be.t_send[0], self.XL * self.KA, 0, self.XL * self.KA)
+        if self.KF:
+            self._xchg(be.t_recv[1], be.t_send[1], self.XL * self.KF, 0, self.XL * self.KF)
+        be.r2c_cols()
         self.primed = False
 
     def set_source_local(self, src_rows):
         self.be.set_source(src_rows)
 
     def vort_local(self):
-        """This rank's rows of vort (record path, main.cpp:273-281)."""
         be = self.be
-        be.phase(PH_C2R_COLS)
-        self._exchange_t(reverse=True)
-        out = be.empty_real()
-        be.phase(PH_C2R_ROWS, real_out=out)
-        return out
+        be.c2r_cols()                                                             # -> t_recv, [dst][XL][ncols]
+        self._xchg(be.t_send[0], be.t_recv[0], self.XL * self.KA, 0, self.XL * self.KA)
+        if self.KF:
+            self._xchg(be.t_send[1], be.t_recv[1], self.XL * self.KF, 0, self.XL * self.KF)
+        return be.c2r_rows()
 
     def step(self, n=1):
         be = self.be
         if n <= 0:
             return
+        fld = self.XL * self.KA
         if not self.primed:
-            be.phase(PH_PRIME)
+            be.prime()                                                            # derivatives of every column; frozen ones final
+            if self.KF:
+                self._xchg(be.w4_recv[1], be.w4_send[1], 4 * self.XL * self.KF, 0, 4 * self.XL * self.KF)
             self.primed = True
+        rows = self.XL // self.row_chunks
         for _ in range(n):
-            for k in range(4):                   # main.cpp:288-317
-                be.phase(PH_COL_BWD)
-                self._exchange_w4()
-                be.phase(PH_ROW)
-                self._exchange_t()
-                be.phase(PH_COL_FWD, stage=k)
+            for k in range(4):                                                    # main.cpp:288-317
+                for kind, arg in stage_schedule(self.nx, self.ny, self.world):
+                    if kind == OP_COL_BWD:
+                        be.col_bwd(4 * arg // self.field_groups, 4 * (arg + 1) // self.field_groups)
+                    elif kind == OP_XCHG_W4:
+                        f0, f1 = 4 * arg // self.field_groups, 4 * (arg + 1) // self.field_groups
+                        self._xchg(be.w4_recv[0], be.w4_send[0], 4 * fld, f0 * fld, (f1 - f0) * fld)
+                    elif kind == OP_ROW:
+                        be.row(arg * rows, rows)
+                    elif kind == OP_XCHG_T:
+                        self._xchg(be.t_recv[0], be.t_send[0], fld, arg * rows * self.KA, rows * self.KA)
+                    else:
+                        be.col_fwd(k)
 
     def close(self):
         self.be.close()
