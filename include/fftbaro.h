@@ -33,6 +33,9 @@ extern "C" {
 const char *fb_strerror(int status);
 const char *fb_last_error(void);          /* thread-local detail of the last failure */
 int fb_version(void);                      /* 100*major + minor                       */
+/* one process per GPU: pick this process's (this thread's) device before creating a context; hipGetDeviceCount / hipSetDevice */
+int fb_device_count(int *count);
+int fb_set_device(int ordinal);
 /* 1 if (nx,ny) is supported: each a power of two in [64, 16384] or 3*2^k in [192, 3072]
  * (the reference's default NPTS = 768, configuration.hpp:18) */
 int fb_size_supported(int nx, int ny);
@@ -194,6 +197,8 @@ int fb_slab_connect_callback(fb_slab *s, fb_alltoall_fn fn, void *user);
 int fb_slab_set_vort_local(fb_slab *s, const float *d_rows);
 int fb_slab_set_source_local(fb_slab *s, const float *d_rows);
 int fb_slab_get_vort_local(fb_slab *s, float *d_rows);
+/* the stage-0 record dumps psi, u, v (main.cpp:181-222) on this rank's rows; any may be NULL */
+int fb_slab_get_diag_local(fb_slab *s, float *d_psi, float *d_u, float *d_v);
 int fb_slab_step(fb_slab *s, int nsteps);
 int fb_slab_synchronize(fb_slab *s);
 int fb_slab_time_steps(fb_slab *s, int nsteps, float *total_ms);

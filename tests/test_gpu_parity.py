@@ -459,3 +459,153 @@ def test_config3_1000_steps_stay_physical(X):
         e_prev = e
     assert m.spectrum()[0, 0].item() == s0
     assert float(v.max()) < 1.05 * float(v0.max()) and float(v.min()) > -0.05 * float(v0.max())
+
+
+# ---------------------------------------------------------------------------------------------------
+# the headline configuration (BASELINE configs[2]: 4096^2 Kuo2004, dt = 0.75 s) at the north-star horizon
+# ---------------------------------------------------------------------------------------------------
+def test_config3_1000_steps_tolerance_4096(X, R):
+    """North star: vorticity within 1e-5 relative L2 of the CPU path after 1000 RK4 steps (main.cpp:259-317), at the headline grid,
+    on the default path (k_row8 + k_col_full).  The CPU side is the committed fixture tests/golden/oracle_4096_step1000.npz: the
+    oracle (C restatement of main.cpp:146-317) run for 1000 steps in the build container by tests/golden/make_long_fixtures.py,
+    every 16th point in x and y plus the full-field L2 norm and sum at steps 100, 500 and 1000."""
+    G = np.load(os.path.join(HERE, "golden", "oracle_4096_step1000.npz"))
+    n = 4096
+    m = X.Model(n, n, dt=0.75)
+    m.set_vort(X.make_field("kuo2004", n))
+    done = 0
+    for upto in (100, 500, 1000):
+        m.step(upto - done)
+        done = upto
+        v = m.vort()
+        got = v[::16, ::16].cpu().numpy()
+        err = R.rel_l2(got, G["vort_sub16_step%d" % upto])
+        l2 = float(v.double().pow(2).sum().sqrt())
+        tot = float(v.double().sum())
+        assert err < 1e-5, (upto, err)
+        assert abs(l2 / float(G["l2_step%d" % upto]) - 1) < 1e-5, upto
+        assert abs(tot / float(G["sum_step%d" % upto]) - 1) < 1e-5, upto                  # mean vorticity: conserved, and the same on both sides
+
+
+_NOISE_CHILD = (
+    "import sys, numpy as np; sys.path[:0]=[%r, %r]\n"
+    "import xlab_fftbarotropic_amd as X\n"
+    "n = 4096; rng = np.random.default_rng(29)\n"
+    "v0 = (rng.standard_normal((n, n)) * 1e-4).astype(np.float32)          # NOT dealiased: energy in every masked mode and in the ky = n/2 column\n"
+    "v0 += X.make_field('kuo2004', n)\n"
+    "src = (rng.standard_normal((n, n)) * 1e-9).astype(np.float32)\n"
+    "m = X.Model(n, n, dt=0.75); m.set_vort(v0); m.set_source(src); m.step(int(sys.argv[1]))\n"
+    "psi, u, v = m.diag()\n"
+    "np.savez(sys.argv[2], vort=m.vort().cpu().numpy()[::4, ::4], spec=m.spectrum().cpu().numpy()[:, ::3], u=u.cpu().numpy()[::8, ::8], psi=psi.cpu().numpy()[::8, ::8])\n"
+)
+
+
+def _noise_run(env, steps, tmpdir, tag):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("FB_FULL_PASS", "FB_FULL_NOSKIP", "FB_NO_COLUMN_SKIP", "FB_NO_ROW8"):
+        e.pop(k, None)
+    e.update(env)
+    out = os.path.join(tmpdir, tag + ".npz")
+    subprocess.check_call([sys.executable, "-c", _NOISE_CHILD % (os.path.dirname(HERE), HERE), str(steps), out], env=e)
+    return np.load(out)
+
+
+def test_frozen_mode_shortcuts_are_bitwise_neutral_4096(O, R):
+    """The shortcuts that rest on SURVEY note N1 (masked modes never change) at the headline grid, with state at EVERY masked
+    wavenumber (white noise that was never dealiased, plus a source).  Three-kernel path: skipping the frozen column tiles
+    against FB_NO_COLUMN_SKIP=1 is bit for bit in vort(), spectrum() and diag() (same kernels either way).  Single-pass path:
+    k_col_full's frozen-tile early return against FB_FULL_NOSKIP=1 agrees to rounding only -- the skipped tiles keep the
+    derivative fields of the priming pass, which transforms them as 64 x 64 where k_col_full would use 16 x 16 x 16 -- while
+    the frozen state itself is bit-identical.  Both designs against each other and against the oracle to rounding."""
+    import tempfile
+    steps = 3
+    with tempfile.TemporaryDirectory() as d:
+        full = _noise_run({}, steps, d, "full")
+        full_ns = _noise_run({"FB_FULL_NOSKIP": "1"}, steps, d, "full_ns")
+        three = _noise_run({"FB_FULL_PASS": "0"}, steps, d, "three")
+        three_ns = _noise_run({"FB_FULL_PASS": "0", "FB_NO_COLUMN_SKIP": "1"}, steps, d, "three_ns")
+    for k in ("vort", "spec", "u", "psi"):
+        assert np.array_equal(three[k].view(np.uint32), three_ns[k].view(np.uint32)), k
+        assert R.rel_l2(full[k].view(np.float32), full_ns[k].view(np.float32)) < 2e-6, k
+        assert R.rel_l2(full[k].view(np.float32), three[k].view(np.float32)) < 2e-6, k
+    assert np.array_equal(full["spec"][:, -20:].view(np.uint32), full_ns["spec"][:, -20:].view(np.uint32))       # frozen modes: untouched either way
+    n = 4096
+    rng = np.random.default_rng(29)
+    v0 = (rng.standard_normal((n, n)) * 1e-4).astype(np.float32)
+    v0 += O.make_field("kuo2004", n)
+    src = (rng.standard_normal((n, n)) * 1e-9).astype(np.float32)
+    mo = O.Model(n, n, dt=0.75)
+    mo.set_vort(v0)
+    mo.set_source(src)
+    mo.step(steps)
+    assert R.rel_l2(full["vort"], mo.vort()[::4, ::4]) < 1e-5
+    so = mo.spectrum()[:, ::3]
+    assert R.rel_l2(full["spec"].view(np.float32), so.view(np.float32)) < 1e-5
+    hi = so[:, -20:]                                     # columns ky >= 1990: all masked -> frozen at their initial value
+    assert np.array_equal(full["spec"][:, -20:].view(np.uint32), three["spec"][:, -20:].view(np.uint32))
+    assert R.rel_l2(full["spec"][:, -20:].view(np.float32), hi.view(np.float32)) < 1e-6
+    psi, u, v = mo.diag()
+    assert R.rel_l2(full["u"], u[::8, ::8]) < 1e-5 and R.rel_l2(full["psi"], psi[::8, ::8]) < 1e-5
+
+
+def test_single_pass_and_three_kernel_paths_agree_over_600_steps_4096(R):
+    """600 steps of the headline configuration on the default path (k_col_full) and on the three-kernel x pass: the same maths
+    with two FFT factorisations stays within the north-star bar of each other at the 1000-step class horizon."""
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, numpy as np; sys.path[:0]=[%r, %r]\n"
+        "import xlab_fftbarotropic_amd as X\n"
+        "n=4096; m=X.Model(n,n,dt=0.75); m.set_vort(X.make_field('kuo2004', n)); m.step(600)\n"
+        "np.save(sys.argv[1], m.vort().cpu().numpy()[::2, ::2])\n"
+    ) % (os.path.dirname(HERE), HERE)
+    with tempfile.TemporaryDirectory() as d:
+        outs = {}
+        for flag in ("1", "0"):
+            a = os.path.join(d, "v%s.npy" % flag)
+            subprocess.check_call([sys.executable, "-c", code, a], env=dict(os.environ, FB_FULL_PASS=flag))
+            outs[flag] = np.load(a)
+    assert np.isfinite(outs["1"]).all()
+    assert R.rel_l2(outs["1"], outs["0"]) < 5e-6
+
+
+@pytest.mark.parametrize("nx,ny", [(256, 8192), (128, 16384)])
+def test_rowh_matches_stockham_row_kernel(O, R, nx, ny):
+    """fb_rowh.h (default at ny = 8192 and 16384: one real row per half-size complex transform) against the Stockham row kernel
+    (FB_NO_ROWH=1) and the oracle -- with a vorticity source, which k_rowh reads in its own digit-reversed order.
+    Child processes: the switch is read when the context is created."""
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, numpy as np; sys.path[:0]=[%r, %r]\n"
+        "import xlab_fftbarotropic_amd as X\n"
+        "nx, ny = %d, %d\n"
+        "rng = np.random.default_rng(5); v0 = rng.standard_normal((nx, ny)).astype(np.float32) * 1e-4\n"
+        "src = rng.standard_normal((nx, ny)).astype(np.float32) * 1e-9\n"
+        "m = X.Model(nx, ny, dt=0.375); m.set_vort(v0); m.set_source(src); m.step(3)\n"
+        "np.save(sys.argv[1], m.vort().cpu().numpy())\n"
+    ) % (os.path.dirname(HERE), HERE, nx, ny)
+    with tempfile.TemporaryDirectory() as d:
+        outs = {}
+        for flag in ("", "1"):
+            env = dict(os.environ)
+            env.pop("FB_NO_ROWH", None)
+            if flag:
+                env["FB_NO_ROWH"] = flag
+            a = os.path.join(d, "v%s.npy" % flag)
+            subprocess.check_call([sys.executable, "-c", code, a], env=env)
+            outs[flag] = np.load(a)
+    assert np.isfinite(outs[""]).all()
+    assert R.rel_l2(outs[""], outs["1"]) < 2e-6
+    rng = np.random.default_rng(5)
+    v0 = rng.standard_normal((nx, ny)).astype(np.float32) * 1e-4
+    src = rng.standard_normal((nx, ny)).astype(np.float32) * 1e-9
+    mo = O.Model(nx, ny, dt=0.375)
+    mo.set_vort(v0)
+    mo.set_source(src)
+    mo.step(3)
+    assert R.rel_l2(outs[""], mo.vort()) < 1e-5

@@ -397,3 +397,64 @@ def test_record_files_have_the_plotting_layout(tmp_path):
     # cyclones, eastward south of them) and vanishes along the row through the centres
     assert u[c + r, c] < -5 and u[c - r, c] > 5 and abs(u[c + r, c] + u[c - r, c]) < 1e-2
     assert abs(u[c, c + r]) < 1e-2 and abs(u[c, c - r]) < 1e-2
+
+
+def test_fifo_producer_emits_one_ranks_rows():
+    """vort_src_input.out --world P --rank r (multi-GPU runs feed one FIFO per rank): flags as usual, fields cut to that rank's rows."""
+    _build()
+    exe = os.path.join(HOST, "vort_src_input.out")
+    n = 64
+    args = ["--npts", str(n), "--dt", "3", "--steps", "12", "--beg-time", "9", "--duration", "12"]
+    full = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    fld = np.frombuffer(full[3:3 + 4 * n * n], dtype="<f4").reshape(n, n)
+    assert fld.max() > 0
+    for r in range(4):
+        part = subprocess.run([exe] + args + ["--world", "4", "--rank", str(r)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        rows = fld[r * 16:(r + 1) * 16].tobytes()
+        assert part == b"\x00" * 2 + b"\x01" + rows + b"\x00" * 3 + b"\x01" + bytes(len(rows)) + b"\x00" * 4
+
+
+@pytest.mark.gpu
+def test_driver_four_ranks_as_threads_match_the_single_gpu_run(tmp_path):
+    """barotropic_main.out --world 4 --ranks-as-threads (all ranks of the multi-GPU flow inside one process on this one GPU:
+    per-rank row ranges of the input and record files, per-rank FIFO sources, engine-driven transposes) against the
+    single-GPU run of the same configuration: same ./log, same step lines, record files equal (vort bit for bit)."""
+    import oracle_py as O
+    import ref_numpy as R
+    _build()
+    n, steps, world = 512, 201, 4
+    exe, prod = os.path.join(HOST, "barotropic_main.out"), os.path.join(HOST, "vort_src_input.out")
+    src_args = ["--npts", str(n), "--dt", "3", "--steps", str(steps), "--beg-time", "150", "--duration", "300"]   # on at step 50, off at 150
+    outs = {}
+    for tag in ("one", "four"):
+        d = tmp_path / tag
+        (d / "input").mkdir(parents=True)
+        (d / "output").mkdir()
+        O.make_field("kuo2004", n).tofile(str(d / "input" / "initial_vorticity.bin"))
+        procs = []
+        if tag == "one":
+            os.mkfifo(str(d / "fifo"))
+            procs.append(subprocess.Popen("%s %s > fifo" % (prod, " ".join(src_args)), shell=True, cwd=str(d), stderr=subprocess.DEVNULL))
+            extra = []
+        else:
+            for r in range(world):
+                os.mkfifo(str(d / ("fifo.%d" % r)))
+                procs.append(subprocess.Popen("%s %s --world %d --rank %d > fifo.%d" % (prod, " ".join(src_args), world, r, r), shell=True,
+                                              cwd=str(d), stderr=subprocess.DEVNULL))
+            extra = ["--world", str(world), "--ranks-as-threads"]
+        res = subprocess.run([exe, "--npts", str(n), "--steps", str(steps), "-f", "fifo"] + extra, cwd=str(d), stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, timeout=600)
+        for p in procs:
+            p.wait(timeout=60)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs[tag] = (res.stdout, (d / "log").read_text())
+    assert outs["four"][0] == outs["one"][0] and outs["four"][1] == outs["one"][1]
+    assert "# Step 200, time = 600.00, record now!" in outs["one"][0] and len(outs["one"][1].split()) == 15
+    rd = lambda tag, f: np.fromfile(str(tmp_path / tag / "output" / f), dtype="<f4")
+    for step in (0, 100, 200):
+        a, b = rd("one", "vort_step_%d.bin" % step), rd("four", "vort_step_%d.bin" % step)
+        assert a.size == n * n and np.array_equal(a.view(np.uint32), b.view(np.uint32)), step
+        assert np.array_equal(rd("one", "vort_src_input_step_%d.bin" % step), rd("four", "vort_src_input_step_%d.bin" % step))
+        for name in ("psi", "u", "v"):
+            assert R.rel_l2(rd("four", "%s_step_%d.bin" % (name, step)), rd("one", "%s_step_%d.bin" % (name, step))) < 1e-6, (name, step)
+    assert rd("one", "vort_src_input_step_100.bin").max() > 0 and rd("one", "vort_src_input_step_200.bin").max() == 0

@@ -49,6 +49,8 @@ def lib():
     L.fb_last_error.restype = C.c_char_p
     L.fb_version.restype = ip
     L.fb_size_supported.argtypes = [ip, ip]
+    L.fb_device_count.argtypes = [C.POINTER(ip)]
+    L.fb_set_device.argtypes = [ip]
     L.fb_create.argtypes = [C.POINTER(vp), ip, ip, C.c_float, C.c_float]
     L.fb_destroy.argtypes = [vp]
     L.fb_set_stream.argtypes = [vp, vp]
@@ -96,6 +98,7 @@ def lib():
     L.fb_slab_set_vort_local.argtypes = [vp, fp]
     L.fb_slab_set_source_local.argtypes = [vp, fp]
     L.fb_slab_get_vort_local.argtypes = [vp, fp]
+    L.fb_slab_get_diag_local.argtypes = [vp, fp, fp, fp]
     L.fb_slab_step.argtypes = [vp, ip]
     L.fb_slab_synchronize.argtypes = [vp]
     L.fb_slab_time_steps.argtypes = [vp, ip, C.POINTER(C.c_float)]
@@ -110,7 +113,7 @@ def lib():
 
 
 EXPORTS = [
-    "fb_strerror", "fb_last_error", "fb_version", "fb_size_supported", "fb_create", "fb_destroy", "fb_set_stream",
+    "fb_strerror", "fb_last_error", "fb_version", "fb_size_supported", "fb_device_count", "fb_set_device", "fb_create", "fb_destroy", "fb_set_stream",
     "fb_synchronize", "fb_get_tables", "fb_malloc", "fb_free", "fb_memcpy_h2d", "fb_memcpy_d2h", "fb_memset0",
     "fb_gradx", "fb_grady", "fb_laplacian", "fb_invert_laplacian", "fb_dealiase", "fb_r2c", "fb_c2r",
     "fb_backward_normalize", "fb_negate", "fb_jacobian", "fb_spec_axpy", "fb_spec_evolve", "fb_spec_rk4_combine",
@@ -119,7 +122,7 @@ EXPORTS = [
     "fb_model_time_steps", "fb_model_profile_steps", "fb_write_field", "fb_read_field", "fb_make_field", "fb_make_source_kuo2004",
     "fb_create_slab", "fb_slab_unique_id", "fb_slab_create", "fb_slab_destroy", "fb_slab_connect_rccl", "fb_local_hub_create",
     "fb_local_hub_destroy", "fb_slab_connect_local", "fb_slab_connect_callback", "fb_slab_set_vort_local", "fb_slab_set_source_local",
-    "fb_slab_get_vort_local", "fb_slab_step", "fb_slab_synchronize", "fb_slab_time_steps", "fb_slab_transport_selftest", "fb_slab_info", "fb_slab_geometry", "fb_slab_plan",
+    "fb_slab_get_vort_local", "fb_slab_get_diag_local", "fb_slab_step", "fb_slab_synchronize", "fb_slab_time_steps", "fb_slab_transport_selftest", "fb_slab_info", "fb_slab_geometry", "fb_slab_plan",
     "fb_malloc_host", "fb_free_host", "fb_stream_create", "fb_stream_destroy", "fb_stream_synchronize", "fb_event_create",
     "fb_event_destroy", "fb_event_record", "fb_stream_wait_event", "fb_event_synchronize", "fb_memcpy_d2h_async",
 ]

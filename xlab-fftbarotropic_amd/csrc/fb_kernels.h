@@ -110,6 +110,27 @@ __global__ void __launch_bounds__(256) k_spec_relayout(const cf *__restrict__ in
     }
 }
 
+// record path of the multi-GPU model: psi_c = invertLaplacian(vort_c) and its derivatives, in place on one column group's
+// 3-pass private layout (row N2*c + d holds kx = c + N1*d; local column j holds ky = ky0 + j).  MODE 0: psi_c (main.cpp:179),
+// 1: grady(psi_c) (main.cpp:198), 2: gradx(psi_c) (main.cpp:212).  Same float32 forms as k_spec_op (no contraction).
+template <int MODE>
+__global__ void __launch_bounds__(256) k_psi_private(SpecCoef c, cf *__restrict__ z, int P, int N1, int N2, int ky0)
+{
+#pragma clang fp contract(off)
+    const size_t total = (size_t)c.nx * P;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / P), col = (int)(idx - (size_t)row * P);
+        const int cc = row / N2, d = row - cc * N2, i = cc + N1 * d, j = ky0 + col;
+        cf a = z[idx];
+        if (j >= c.hy) { z[idx] = cf_make(0.f, 0.f); continue; }                      // pad columns
+        const float li = (i == 0 && j == 0) ? 1.0f : coef_lap(c, i, j);               // fftwfop.cpp:42-43,112-117
+        a = cf_make(a.x / li, a.y / li);
+        if (MODE == 1) { const float k = c.gy[j]; a = cf_make(-a.y * k, a.x * k); }   // fftwfop.cpp:96-103
+        if (MODE == 2) { const float k = c.gx[i]; a = cf_make(-a.y * k, a.x * k); }   // fftwfop.cpp:87-94
+        z[idx] = a;
+    }
+}
+
 // State arrays (vort_c0, stage state, RK accumulator) are touched by k_col_mid only, so they live
 // in that kernel's register order ("tile-major"): tile (cb, ct) = N2 rows x 16 columns is contiguous,
 //   complex index = ((tile*(NLB/2) + e/2)*64 + lane)*2 + (e & 1),   e = 8 s + q  <->  row d = h + 4 s + R1 q,

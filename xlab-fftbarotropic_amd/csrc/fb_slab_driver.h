@@ -246,17 +246,23 @@ extern "C" int fb_slab_set_source_local(fb_slab *s, const float *d_rows)
     return fb_model_set_source(s->m, d_rows);               // this rank's [XL][ny] rows of vort_src (main-shallow-water.cpp:304), NULL = zeros
 }
 
-extern "C" int fb_slab_get_vort_local(fb_slab *s, float *d_rows)
+// spectral field (a function of vort_c, selected by `what`) -> this rank's rows of the physical field * scale:
+// x transform of the local columns -> transpose in the reverse roles -> y transform of the local rows
+static int slab_c2r_of_state(fb_slab *s, int what, float scale, float *d_rows)
 {
-    SLAB_READY(s);
-    if (!d_rows) return fail(FB_EINVAL, "fb_slab_get_vort_local: NULL");
     fb_ctx *c = s->c; fb_model *m = s->m;
     int rc;
-    // record path, main.cpp:273-281: copy of vort_c, x transform of the local columns -> transpose (reverse roles) -> y transform of the local rows
     for (int g = 0; g < c->ngroups; ++g) {
         const ColGroup &G = c->grp[g];
-        if ((rc = state_convert(c, G, m->gb[g].ZA, m->gb[g].t_recv, false))) return rc;
-        if ((rc = launch_col_block<+1>(c, G, m->gb[g].t_recv, 1, 0)) || (rc = launch_col_strided<+1>(c, G, m->gb[g].t_recv, 1, 0))) return rc;   // natural [x][ncols] == [dst][XL][ncols]
+        cf *w = m->gb[g].t_recv;
+        if ((rc = state_convert(c, G, m->gb[g].ZA, w, false))) return rc;           // copy of vort_c (main.cpp:273)
+        const size_t total = grp_elems(c, G);
+        const dim3 grid(grid_for(c, total)), blk(256);
+        if (what == 1) hipLaunchKernelGGL((k_psi_private<0>), grid, blk, 0, c->stream, make_coef(c), w, G.ncols, c->N1, c->N2, G.ky0);
+        else if (what == 2) hipLaunchKernelGGL((k_psi_private<1>), grid, blk, 0, c->stream, make_coef(c), w, G.ncols, c->N1, c->N2, G.ky0);
+        else if (what == 3) hipLaunchKernelGGL((k_psi_private<2>), grid, blk, 0, c->stream, make_coef(c), w, G.ncols, c->N1, c->N2, G.ky0);
+        HIPCHK(hipGetLastError());
+        if ((rc = launch_col_block<+1>(c, G, w, 1, 0)) || (rc = launch_col_strided<+1>(c, G, w, 1, 0))) return rc;   // natural [x][ncols] == [dst][XL][ncols]
     }
     if ((rc = slab_after(s->comm, s->comp, s->ev_misc[0]))) return rc;
     for (int g = 0; g < c->ngroups; ++g) {
@@ -266,8 +272,27 @@ extern "C" int fb_slab_get_vort_local(fb_slab *s, float *d_rows)
     if ((rc = slab_after(s->comp, s->comm, s->ev_misc[1]))) return rc;
     RowArgs a = row_args_base(c);
     a.M = c->world == 1 ? view_single(c, m->gb[0].t_send, 0) : view_slab(c, m->gb[0].t_send, m->gb[1].t_send, 1);
-    a.rout = d_rows; a.scale = 1.0f / (float)((size_t)c->nx * c->ny);
+    a.rout = d_rows; a.scale = scale;
     return launch_row<ROW_INV>(c, a);
+}
+
+extern "C" int fb_slab_get_vort_local(fb_slab *s, float *d_rows)
+{
+    SLAB_READY(s);
+    if (!d_rows) return fail(FB_EINVAL, "fb_slab_get_vort_local: NULL");
+    return slab_c2r_of_state(s, 0, 1.0f / (float)((size_t)s->c->nx * s->c->ny), d_rows);      // record path, main.cpp:273-281
+}
+
+// the stage-0 record dumps of main.cpp:181-222 on this rank's rows (any may be NULL): psi, u = -dpsi/dy, v = dpsi/dx
+extern "C" int fb_slab_get_diag_local(fb_slab *s, float *d_psi, float *d_u, float *d_v)
+{
+    SLAB_READY(s);
+    const float g = 1.0f / (float)((size_t)s->c->nx * s->c->ny);
+    int rc;
+    if (d_psi && (rc = slab_c2r_of_state(s, 1, g, d_psi))) return rc;
+    if (d_u && (rc = slab_c2r_of_state(s, 2, -g, d_u))) return rc;                  // normalise, then negate (SURVEY note N3): (x * g) * -1 == x * (-g) exactly
+    if (d_v && (rc = slab_c2r_of_state(s, 3, g, d_v))) return rc;
+    return FB_OK;
 }
 
 // ---- the step ----

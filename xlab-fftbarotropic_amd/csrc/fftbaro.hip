@@ -16,6 +16,7 @@
 #include "fb_col_full.h"
 #include "fb_row3.h"
 #include "fb_row8.h"
+#include "fb_rowh.h"
 
 // --------------------------------------------------------------------------------------------
 // errors
@@ -44,7 +45,15 @@ extern "C" const char *fb_strerror(int s)
 }
 extern "C" const char *fb_last_error(void) { return g_last_error.c_str(); }
 extern "C" void fb_internal_set_error(const char *msg) { g_last_error = msg ? msg : ""; }   // fb_fieldio.cpp, fb_slab_comm.cpp
-extern "C" int fb_version(void) { return 100; }
+extern "C" int fb_version(void) { return 200; }
+extern "C" int fb_device_count(int *count)
+{
+    if (!count) return fail(FB_EINVAL, "fb_device_count: NULL");
+    *count = 0;
+    HIPCHK(hipGetDeviceCount(count));
+    return FB_OK;
+}
+extern "C" int fb_set_device(int ordinal) { HIPCHK(hipSetDevice(ordinal)); return FB_OK; }
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 // powers of two 64..16384, or 3*2^k in 192..3072 (the reference's default NPTS = 768)
@@ -78,6 +87,8 @@ struct fb_ctx {
     cf *d_tw_n1, *d_tw_n2, *d_tw_big, *d_tw_row_bwd, *d_tw_row_fwd, *d_tw_256;
     cf *d_tw_row3;              // W_ny^j for ny = 3*M (row pass = radix 3 x three length-M transforms) and ny = 4096 (k_row8), else NULL
     bool use_row8;              // fused row pass of ny = 4096 through k_row8 (FB_NO_ROW8=1: the Stockham kernel)
+    int rowh_v;                 // fused row pass of ny = 8192 (1) / 16384 (2) through k_rowh (FB_NO_ROWH=1: 0 = the Stockham kernel)
+    cf *d_tw_4096;              // W_4096^j for k_rowh's sub-transforms
     int pace_strided;           // pace the strided sub-pass's accesses (fields much larger than the caches)
     int col_chunks;             // x pass of a stage is issued in this many column chunks ...
     int col_streams;            // ... round-robin over this many streams, so that one chunk's kernel tails are filled by the next chunk
@@ -259,8 +270,10 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
         (rc = upload(&c->d_tw_row_fwd, make_row_table(ny % 3 ? ny : ny / 3, plan_radices_rt(ny % 3 ? ny : ny / 3, true))))) {
         fb_destroy(c); return rc;
     }
-    if ((ny % 3 == 0 || ny == 4096) && (rc = upload(&c->d_tw_row3, make_root_table(ny)))) { fb_destroy(c); return rc; }   // 4096: k_row8's W_ny^j
+    if ((ny % 3 == 0 || ny >= 4096) && (rc = upload(&c->d_tw_row3, make_root_table(ny)))) { fb_destroy(c); return rc; }   // 4096: k_row8's W_ny^j; 8192, 16384: k_rowh's
     c->use_row8 = ny == 4096 && !getenv("FB_NO_ROW8");
+    c->rowh_v = (ny == 8192 || ny == 16384) && !getenv("FB_NO_ROWH") ? ny / 8192 : 0;
+    if (c->rowh_v && (rc = upload(&c->d_tw_4096, make_root_table(4096)))) { fb_destroy(c); return rc; }
     hipDeviceProp_t prop;
     if (hipGetDevice(&c->dev) != hipSuccess || hipGetDeviceProperties(&prop, c->dev) != hipSuccess) {
         fb_destroy(c); return fail(FB_EHIP, "fb_create: cannot query the device");
@@ -274,7 +287,7 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
 extern "C" int fb_destroy(fb_ctx *c)
 {
     if (!c) return FB_OK;
-    void *tabs[] = {c->d_gx, c->d_kx2, c->d_gy, c->d_ky2, c->d_tw_n1, c->d_tw_n2, c->d_tw_big, c->d_tw_row_bwd, c->d_tw_row_fwd, c->d_tw_256, c->d_tw_row3};
+    void *tabs[] = {c->d_gx, c->d_kx2, c->d_gy, c->d_ky2, c->d_tw_n1, c->d_tw_n2, c->d_tw_big, c->d_tw_row_bwd, c->d_tw_row_fwd, c->d_tw_256, c->d_tw_row3, c->d_tw_4096};
     for (void *t : tabs) if (t) hipFree(t);
     if (c->d_scratch) hipFree(c->d_scratch);
     for (int i = 0; i < 3; ++i) { if (c->aux[i]) hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]); }
@@ -510,10 +523,25 @@ static int launch_row8(fb_ctx *c, const RowArgs &a)
     return FB_OK;
 }
 
+template <int V> static int launch_rowh(fb_ctx *c, const RowArgs &a)
+{
+    int grid = a.nx, cap = c->max_wg / (4 * V);   // resident workgroups: two per CU at ny = 8192, one at 16384; each loops over rows
+    if (const char *e = getenv("FB_ROW_GRID")) { int v = atoi(e); if (v >= 64) cap = v; }
+    if (grid > cap) grid = cap;
+    auto kern = c->world > 1 ? k_rowh<V, true> : k_rowh<V, false>;
+    int rc = set_max_lds(c, (const void *)kern, RowH<V>::LDS_BYTES);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), RowH<V>::LDS_BYTES, c->stream, a, (const cf *)c->d_tw_4096, (const cf *)c->d_tw_row3);
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
 template <int MODE> static int launch_row(fb_ctx *c, const RowArgs &a)
 {
     if (a.nx <= 0) return FB_OK;
     if (MODE == ROW_FUSED && c->use_row8 && a.nx >= 2) return launch_row8(c, a);
+    if (MODE == ROW_FUSED && c->rowh_v == 1) return launch_rowh<1>(c, a);
+    if (MODE == ROW_FUSED && c->rowh_v == 2) return launch_rowh<2>(c, a);
     switch (c->ny) {
     case 192: return launch_row3_t<64, MODE>(c, a);
     case 384: return launch_row3_t<128, MODE>(c, a);
@@ -899,6 +927,13 @@ extern "C" int fb_model_set_source(fb_model *m, const float *d_src)
     const size_t n = (size_t)c->XL * c->ny * sizeof(float);       // the caller's local rows
     if (!d_src) { if (m->src) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(m->src); m->src = nullptr; } return FB_OK; }
     if (!m->src && hipMalloc((void **)&m->src, n) != hipSuccess) return fail(FB_ENOMEM, "source allocation failed");
+    if (c->rowh_v) {                                              // k_rowh reads vort_src in its own physical-space order
+        const size_t pairs = (size_t)c->XL * c->ny / 2;
+        if (c->rowh_v == 1) hipLaunchKernelGGL((k_rowh_permute_src<1>), dim3(grid_for(c, pairs)), dim3(256), 0, c->stream, d_src, m->src, c->XL);
+        else hipLaunchKernelGGL((k_rowh_permute_src<2>), dim3(grid_for(c, pairs)), dim3(256), 0, c->stream, d_src, m->src, c->XL);
+        HIPCHK(hipGetLastError());
+        return FB_OK;
+    }
     HIPCHK(hipMemcpyAsync(m->src, d_src, n, hipMemcpyDeviceToDevice, c->stream));
     return FB_OK;
 }

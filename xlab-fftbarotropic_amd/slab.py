@@ -185,6 +185,14 @@ class EngineSlab:
         self.synchronize()
         return out
 
+    def diag_local(self):
+        """This rank's rows of psi, u, v (the stage-0 record dumps, main.cpp:181-222)."""
+        t = self.torch
+        psi, u, v = (t.empty((self.XL, self.ny), dtype=t.float32, device="cuda") for _ in range(3))
+        self.B.check(self.L.fb_slab_get_diag_local(self._h, C.c_void_p(psi.data_ptr()), C.c_void_p(u.data_ptr()), C.c_void_p(v.data_ptr())))
+        self.synchronize()
+        return psi, u, v
+
     def time_steps(self, n):
         ms = C.c_float()
         self.B.check(self.L.fb_slab_time_steps(self._h, n, C.byref(ms)))
