@@ -1,4 +1,4 @@
-// fb_col_full.h -- single-pass x-transform + spectral update for nx = 4096 (one GPU); the default there.
+// fb_col_full.h -- single-pass x-transform + spectral update for nx = 4096 and nx = 8192 (one GPU); the default there.
 //
 // Replaces the three column kernels of a stage (k_col_strided<-1>, k_col_mid, k_col_strided<+1>:
 // 17.5 C of measured traffic) by one kernel that moves 11.3-13.7 C: a 1024-thread workgroup keeps a whole
@@ -18,14 +18,22 @@
 // same XCD so that the two halves of every 128-B line meet in one L2 (tools/mb_strided.hip:
 // 3.8-3.9 TB/s with that placement against 2.6-3.0 TB/s without).
 //
-// The ky = ny/2 column is not handled here: on square grids it lies outside the dealiasing circle
-// (fftwfop.cpp:57-61), so its tendency is always masked, its state never changes (SURVEY note N1)
-// and its four derivative columns in W4 stay what the priming pass wrote.  That makes the column
-// count a power of two (ny/2 = 256 tiles of 8 at 4096^2: one tile per CU, no tail).  Tiles that lie
-// entirely outside the circle (ky >= 1936 at 4096^2) are skipped for the same reason.
+// nx = 8192 = 2 x 4096 (NSUB = 2): workgroup (tile, k1) transforms the 4096 wavenumbers kx = 2 k2 + k1 of its tile; the
+// remaining radix-2 step over x = x2 + 4096 x1 is fused into the row pass (fb_rowh.h, k_rowh<1, 2>), which reads the two
+// "half-transformed" rows Y_k1[x2] of every field and writes the two rows U_k1[x2] of the tendency:
+//     backward  X[x2 + 4096 x1] = Y_0[x2] + (-1)^x1 e^{+2 pi i x2/8192} Y_1[x2],   Y_k1 = IDFT_4096 over k2 of Z[2 k2 + k1]
+//     forward   T[2 k2 + k1]   = DFT_4096 over x2 of U_k1[x2],   U_k1[x2] = e^{-2 pi i k1 x2/8192} (t[x2] + (-1)^k1 t[x2 + 4096])
+// The mixed arrays then hold row k1*4096 + x2; nothing else changes (17.8 C of traffic per stage at 8192^2 instead of 22.4 C).
+//
+// The ky = ny/2 column lies outside the dealiasing circle on these grids (fftwfop.cpp:57-61): its tendency is always
+// masked, its state never changes (SURVEY note N1).  The per-stage launches leave it alone, which makes their column count a
+// power of two (ny/2 = 256 tiles of 8 at 4096^2: one tile per CU, no tail); the PRIME launch (STAGE = 4: derivatives of
+// vort_c only, after the state was set) covers one more tile, [ny/2, ny/2 + 8) = that column plus zero padding, so its four
+// derivative columns are written once.  Tiles that lie entirely outside the circle (ky >= 1936 at 4096^2) are skipped per
+// stage for the same reason -- bit-identical, since the priming launch ran the same code on them.
 //
 // State arrays (ZA, ZB, ACC) use a layout private to this kernel:
-//   [tile][k3][thread] float4 = (column 2c, column 2c+1)   -- fully coalesced, 16 B per lane.
+//   [k1][tile, 0..ntiles][k3][thread] float4 = (column 2c, column 2c+1)   -- fully coalesced, 16 B per lane.
 #pragma once
 #include "fb_kernels.h"
 
@@ -44,13 +52,15 @@ struct FullArgs {
     cf *W4;               // four derivative fields, mixed layout, field f at W4 + f*fstride
     long fstride;
     int P;                // pitch of the mixed arrays
-    int ntiles;           // (ny/2)/8
-    int ntiles_active;    // tiles below this index hold at least one column inside the dealiasing circle; the rest are frozen (note N1)
-    int stage;            // 0..3
+    int ntiles;           // (ny/2)/8; the state arrays hold ntiles + 1 tiles per sub-sequence (the last one: the ky = ny/2 column)
+    int ntiles_run;       // tiles this launch covers: PRIME ntiles + 1; stages: tiles that hold at least one column inside the dealiasing circle, the rest are frozen (note N1)
+    int nsub;             // 1: nx = 4096; 2: nx = 8192 (kx = 2 k2 + k1, see above)
+    int stage;            // 0..3; 4 = PRIME
     float nu, dt;
     SpecCoef coef;
     const cf *tw256;      // W256^m, m < 256
     const cf *tw4096;     // W4096^m (first 256 entries used)
+    long sub_rows;        // rows of the mixed arrays per sub-sequence (4096)
 };
 
 // 16x16 transpose between the wave index and the register index (one column = 8 B per lane)
@@ -179,7 +189,7 @@ FB_DEV void cf_st4(void *ubase, unsigned voff, float4 x) { *reinterpret_cast<flo
 #endif
 FB_DEV void cf_st4_w4(void *ubase, unsigned voff, float4 x) { st4<CF_NT_W4 != 0>(static_cast<char *>(ubase) + voff, x); }
 
-template <int STAGE>
+template <int STAGE, int NSUB>
 __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -191,36 +201,44 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
     const int tid = threadIdx.x, lane = tid & 63, l = lane >> 2, c = lane & 3;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave id, in an SGPR
 
-    // adjacent tiles on one XCD (blocks b and b+8 share an XCD: MI355X_MICROARCH.md, dispatch)
-    int tile = blockIdx.x;
-    if ((a.ntiles & 7) == 0) tile = (blockIdx.x & 7) * (a.ntiles >> 3) + (blockIdx.x >> 3);
-    if (tile >= a.ntiles_active) return;                  // frozen tile: state and derivatives stay what the priming pass left
+    // grid = nsub * ntiles_grid blocks; adjacent tiles on one XCD (blocks b and b+8 share an XCD: MI355X_MICROARCH.md, dispatch)
+    constexpr int nsub = NSUB;
+    const int ntg = gridDim.x / nsub;
+    const int k1 = NSUB == 1 ? 0 : blockIdx.x / ntg, bt = blockIdx.x - k1 * ntg;
+    int tile = bt;
+    if ((ntg & 7) == 0) tile = (bt & 7) * (ntg >> 3) + (bt >> 3);
+    if (tile >= a.ntiles_run) return;                     // frozen tile: state and derivatives stay what the priming launch left
 
     const int ky0 = tile * 8 + 2 * c;                                   // this thread's two columns: ky0, ky0+1
     const unsigned voff_m = (unsigned)((l * a.P + 2 * c) * (int)sizeof(cf));            // mixed arrays: row l of the wave's 16, column pair c
-    const size_t ubase_m = ((size_t)(16 * w) * a.P + (size_t)tile * 8) * sizeof(cf);    // uniform part: rows 16 w.., tile's first column
+    const size_t ubase_m = ((size_t)(k1 * a.sub_rows + 16 * w) * a.P + (size_t)tile * 8) * sizeof(cf);    // uniform part: sub-sequence, rows 16 w.., tile's first column
     const size_t rstep = (size_t)256 * a.P * sizeof(cf);                                // 256 rows, bytes
-    const unsigned voff_s = (unsigned)(lane * (int)sizeof(float4));                     // state arrays: [tile][k3][thread]
-    const size_t ubase_s = (((size_t)tile * 16) * CF_THREADS + (size_t)w * 64) * sizeof(float4);
+    const unsigned voff_s = (unsigned)(lane * (int)sizeof(float4));                     // state arrays: [k1][tile][k3][thread]
+    const size_t ubase_s = ((((size_t)k1 * (a.ntiles + 1) + tile) * 16) * CF_THREADS + (size_t)w * 64) * sizeof(float4);
     const size_t sstep = (size_t)CF_THREADS * sizeof(float4);
 
+    constexpr bool PRIME = STAGE == 4;
     cf v[2][16];
     {   // ---- tendency tile -> registers (rows 256 i + 16 w + l); the tables are filled while these loads travel
         const char *src = reinterpret_cast<const char *>(a.Tin) + ubase_m;
         float4 tin[16];
+        if (!PRIME) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tin[i] = ld4<CF_NT_TIN != 0>(src + i * rstep + voff_m);
+            for (int i = 0; i < 16; ++i) tin[i] = ld4<CF_NT_TIN != 0>(src + i * rstep + voff_m);
+        }
         float g4[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g4[i] = a.coef.gx[tid + i * CF_THREADS];
+        for (int i = 0; i < 4; ++i) g4[i] = a.coef.gx[nsub * (tid + i * CF_THREADS) + k1];      // gradx_coe at kx = nsub k2 + k1
         if (tid < 256) { tabB[tid] = a.tw256[tid]; tabA[tid] = a.tw4096[tid]; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) gxt[tid + i * CF_THREADS] = g4[i];
+        if (!PRIME) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { v[0][i] = cf_make(tin[i].x, tin[i].y); v[1][i] = cf_make(tin[i].z, tin[i].w); }
+            for (int i = 0; i < 16; ++i) { v[0][i] = cf_make(tin[i].x, tin[i].y); v[1][i] = cf_make(tin[i].z, tin[i].w); }
+        }
     }
     __syncthreads();                                            // twiddle tables are in LDS
-    cf_fft4096<-1>(lds, tabA, tabB, v, w, l, c, lane);           // main.cpp:237 (x part)
+    if (!PRIME) cf_fft4096<-1>(lds, tabA, tabB, v, w, l, c, lane);           // main.cpp:237 (x part)
 
     // ---- viscous term, mask, RK stage update: kx = w + 16 l + 256 k3   (main.cpp:148,240-251,296-312)
     const char *Z0 = reinterpret_cast<const char *>(a.Zbase) + ubase_s;
@@ -228,6 +246,7 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
          *ZO = reinterpret_cast<char *>(a.Zout) + ubase_s;
     const double ky2a = a.coef.ky2[ky0], ky2b = a.coef.ky2[ky0 + 1];
     const float gya = a.coef.gy[ky0], gyb = a.coef.gy[ky0 + 1];
+    const bool pada = ky0 >= a.coef.hy, padb = ky0 + 1 >= a.coef.hy;                    // PRIME's last tile: columns beyond ny/2 are zero padding
     constexpr int stage = STAGE;
     const float nu = a.nu, dt = a.dt, hdt = (stage == 2) ? a.dt : a.dt / 2.0f;
     // The state arrays move in batches of two k3: the loads of batch b+1 are issued before the stores of batch b,
@@ -251,15 +270,15 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
             else cf_st4(ZO + k3 * sstep, voff_s, zn);
         }
     };
-    load_batch(0);
+    if (!PRIME) load_batch(0);
 #pragma unroll
-    for (int b = 0; b < NBATCH; ++b) {
+    for (int b = 0; b < (PRIME ? 0 : NBATCH); ++b) {
         float4 accn[KB];
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             const int k3 = b * KB + j;
-            const int ikx = w + 256 * k3 + 16 * l;
-            const float gx = gxt[ikx];
+            const int ik2 = w + 256 * k3 + 16 * l, ikx = nsub * ik2 + k1;
+            const float gx = gxt[ik2];
             const double kx2 = (double)gx * (double)gx;                      // fftwfop.cpp:42,45
             const float lapa = (float)(-(kx2 + ky2a)), lapb = (float)(-(kx2 + ky2b));
             const float mska = coef_mask(a.coef, ikx, ky0), mskb = coef_mask(a.coef, ikx, ky0 + 1);
@@ -293,10 +312,10 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
     }
 
     // ---- four derivatives of the new state, each transformed back and stored (fftwfop.cpp:87-117)
-    const char *ZN = stage < 3 ? ZC : ZO;
+    const char *ZN = PRIME ? Z0 : (stage < 3 ? ZC : ZO);
 #pragma unroll 1
     for (int f = 0; f < 4; ++f) {
-        if (f > 0) {                                  // registers were consumed: fetch the state again (own writes, L2/MALL)
+        if (f > 0 || PRIME) {                         // registers were consumed: fetch the state again (own writes, L2/MALL)
             const unsigned vs = (unsigned)launder((int)voff_s);
 #pragma unroll
             for (int k3 = 0; k3 < 16; ++k3) {
@@ -312,9 +331,10 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
             const float gx = gxt[w + 256 * k3 + lkx];
             if (psi) {                                // psi_c = invertLaplacian(vort_c)   main.cpp:179
                 const double kx2 = (double)gx * (double)gx;
-                const float lia = (w + 256 * k3 + 16 * l == 0 && ky0 == 0) ? 1.0f : (float)(-(kx2 + ky2a));
+                const float lia = (nsub * (w + 256 * k3 + 16 * l) + k1 == 0 && ky0 == 0) ? 1.0f : (float)(-(kx2 + ky2a));
                 const float lib = (float)(-(kx2 + ky2b));
-                za = cf_make(za.x / lia, za.y / lia); zb = cf_make(zb.x / lib, zb.y / lib);
+                za = pada ? cf_make(0.f, 0.f) : cf_make(za.x / lia, za.y / lia);      // (-(kx^2 + 0) = 0 at kx = 0 in a padding column)
+                zb = padb ? cf_make(0.f, 0.f) : cf_make(zb.x / lib, zb.y / lib);
             }
             const float ka = use_gx ? gx : gya, kb = use_gx ? gx : gyb;
             v[0][k3] = cf_make(-za.y * ka, za.x * ka);
@@ -330,21 +350,24 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
     }
 }
 
-// ---- layout conversion: 3-pass private spectral layout (row N2*c+d, pitch P) <-> this kernel's
+// ---- layout conversion: 3-pass private spectral layout (row N2*c+d holds kx = c + N1*d, pitch P) <-> this kernel's
+// [k1][tile 0..ntiles][k3][thread][col]; columns beyond ny/2 (the last tile's padding) are zero
 template <bool TO_FULL>
-__global__ void __launch_bounds__(256) k_full_relayout(const cf *__restrict__ in, cf *__restrict__ out, int P, int N1, int N2, int ntiles)
+__global__ void __launch_bounds__(256) k_full_relayout(const cf *__restrict__ in, cf *__restrict__ out, int P, int N1, int N2, int ntiles, int nsub, int hy)
 {
-    // one thread per (tile, k3, tid, col)
-    const size_t total = (size_t)ntiles * 16 * CF_THREADS * 2;
+    // one thread per (k1, tile, k3, tid, col)
+    const size_t total = (size_t)nsub * (ntiles + 1) * 16 * CF_THREADS * 2;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int col = (int)(idx & 1);
         const int tid = (int)((idx >> 1) & (CF_THREADS - 1));
         const int k3 = (int)((idx >> 11) & 15);
-        const int tile = (int)(idx >> 15);
+        const int st = (int)(idx >> 15);                             // k1 * (ntiles + 1) + tile
+        const int k1 = st / (ntiles + 1), tile = st - k1 * (ntiles + 1);
         const int w = tid >> 6, l = (tid >> 2) & 15, c = tid & 3;
-        const int kx = w + 16 * l + 256 * k3, ky = tile * 8 + 2 * c + col;
+        const int kx = nsub * (w + 16 * l + 256 * k3) + k1, ky = tile * 8 + 2 * c + col;
         const int cc = kx % N1, d = kx / N1;                       // 3-pass layout: row N2*cc + d holds kx = cc + N1*d
         const size_t p3 = (size_t)(N2 * cc + d) * P + ky;
+        if (ky >= hy) { if (TO_FULL) out[idx] = cf_make(0.f, 0.f); continue; }
         if (TO_FULL) out[idx] = in[p3]; else out[p3] = in[idx];
     }
 }

@@ -179,6 +179,9 @@ struct RowArgs {
     int x0, nx;             // local rows [x0, x0 + nx), nx even (a row chunk of the pipelined multi-GPU step, else everything)
     float scale;            // 1/GRIDS (FUSED) ; 1/GRIDS or 1 (INV)
     const cf *tw_bwd, *tw_fwd;
+    // k_rowh2 (nx = 8192 with the radix-2 x step fused into the row pass, fb_col_full.h): rows per sub-sequence and W_nx^j
+    long sub_rows;
+    const cf *tw_x;
 };
 
 template <int N> struct RowCfg {

@@ -313,3 +313,153 @@ __global__ void __launch_bounds__(512, RowH<V>::MIN_WAVES) k_rowh(RowArgs a, con
         }
     }
 }
+
+
+// =====================================================================================================================
+// k_rowh2: ny = 8192 row pass with the last radix-2 step of the x transform fused in (nx = 8192 = 2 x 4096, fb_col_full.h).
+// A 1024-thread workgroup owns one x2: half h (waves 8h .. 8h+7) produces the physical row x = x2 + 4096 h,
+//     X_h[k] = Y_0[x2][k] + (-1)^h e^{+2 pi i x2/8192} Y_1[x2][k]           (both staged rows are read by both halves)
+// runs k_rowh<1>'s five transforms on it, and the halves meet again after the r2c post-processing:
+//     U_0[x2] = T_0 + T_1,   U_1[x2] = e^{-2 pi i x2/8192} (T_0 - T_1)      (half h stores U_h at row 4096 h + x2)
+// Same LDS budget as k_rowh<2>: two exchange buffers + two staged rows = 140 KB, one workgroup (16 waves) per CU.
+// =====================================================================================================================
+struct RowH2 {
+    static constexpr int M = 4096, XSUB = RowH<1>::XSUB, STG = RowH<1>::STG, TW2 = 64;
+    static constexpr size_t LDS_BYTES = (size_t)(2 * XSUB + 2 * STG + TW2) * sizeof(cf);
+};
+
+FB_DEV void rh2_ext(cf *v, int t, const cf *stg0, const cf *stg1, cf wh, cf wx)
+{
+    constexpr int M = RowH2::M;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = t + 512 * e;
+        cf a = cadd(lds_rd(&stg0[k]), cmul(lds_rd(&stg1[k]), wh));                    // X_h[k]
+        cf b = cadd(lds_rd(&stg0[M - k]), cmul(lds_rd(&stg1[M - k]), wh));            // X_h[M-k]
+        if (e == 0 && t == 0) { a.y = 0.f; b.y = 0.f; }                               // k = 0: X[0] and X[M] count as real
+        const cf ev = cf_make(a.x + b.x, a.y - b.y);
+        cf d = cmul(cf_make(a.x - b.x, a.y + b.y), wx);
+        switch (e) {
+        case 1: d = mul_w16<1, +1>(d); break; case 2: d = mul_w16<2, +1>(d); break; case 3: d = mul_w16<3, +1>(d); break;
+        case 4: d = mul_w16<4, +1>(d); break; case 5: d = mul_w16<5, +1>(d); break; case 6: d = mul_w16<6, +1>(d); break;
+        case 7: d = mul_w16<7, +1>(d); break; default: break;
+        }
+        v[e] = cadd_ib(ev, d);
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_rowh2(RowArgs a, const cf *__restrict__ root4096, const cf *__restrict__ rootN /* W_8192^j (y) */)
+{
+    constexpr int M = RowH2::M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *smem = reinterpret_cast<cf *>(smem_raw);
+    const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 9));            // half: wave-uniform
+    const int t = threadIdx.x & 511, w = t >> 6, l = t & 63;
+    cf *xbuf = smem + h * RowH2::XSUB, *xoth = smem + (1 - h) * RowH2::XSUB;
+    cf *stg0 = smem + 2 * RowH2::XSUB, *stg1 = stg0 + RowH2::STG, *stgh = h ? stg1 : stg0;
+    Row8Tw tw;
+#pragma unroll
+    for (int p = 1; p < 8; ++p) { tw.w0[p - 1] = root4096[p * t]; tw.w1[p - 1] = root4096[8 * p * l]; }
+    cf *tw2 = stg1 + RowH2::STG;
+    if (threadIdx.x < 64) tw2[t] = root4096[64 * (t & 7) * (t >> 3)];
+    tw.w2 = tw2;
+    const cf wq = cf_make(1.f, 0.f);
+    cf wx;                                                           // exp(+2 pi i t/N), N = 8192
+    { const cf r = rootN[t]; wx = cf_make(r.x, -r.y); }
+#pragma unroll
+    for (int p = 0; p < 7; ++p) asm volatile("" :: "v"(tw.w0[p]), "v"(tw.w1[p]));
+    asm volatile("" :: "v"(wx));
+    __syncthreads();
+
+    const long sub = a.sub_rows;
+    const int iters = (a.nx + gridDim.x - 1) / gridDim.x;
+    auto row_of = [&](int it, bool &valid) { const int r = it * gridDim.x + blockIdx.x; valid = r < a.nx; return a.x0 + (valid ? r : 0); };
+    if (iters > 0) {
+        bool vld; const int x2 = row_of(0, vld);
+        rh_dma_issue<1, false>(stgh, t, a.M, 0, (int)(h * sub) + x2);
+        RH_WAIT_ROW();
+    }
+    for (int it = 0; it < iters; ++it) {
+        bool valid;
+        const int x2 = row_of(it, valid);
+        bool vn = false;
+        const int xn = (it + 1 < iters) ? row_of(it + 1, vn) : -1;
+        const cf wb = a.tw_x[x2];                                     // W_nx^{x2} (forward sign), wave-uniform
+        const cf wh = h ? cf_make(-wb.x, wb.y) : cf_make(wb.x, -wb.y);   // (-1)^h e^{+2 pi i x2/nx}
+        const int xrow = (int)(h * sub) + x2;                         // physical row x2 + 4096 h == storage row of Y_h / U_h
+        cf v1[1][8];
+        cf (&v)[8] = v1[0];
+        cf p[8];
+        auto c2r_phase = [&](bool wait, int next_field, int next_x2) {
+            const int tp = launder(t);
+            if (wait) RH_WAIT_ROW();
+            lds_barrier();
+            rh2_ext(v, tp, stg0, stg1, wh, wx);
+            lds_barrier();
+            if (next_x2 >= 0) rh_dma_issue<1, false>(stgh, tp, a.M, next_field, (int)(h * sub) + next_x2);
+            rh_bwd<1>(v1, xbuf, tw, wq, tp >> 6, tp & 63);
+        };
+        c2r_phase(false, 2, x2);                                      // d vort/dx                         main.cpp:154
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] = cf_make(v[e].x * a.scale, v[e].y * a.scale);
+        c2r_phase(true, 1, x2);                                       // d psi/dy                          main.cpp:200-201,225
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] = cf_make((v[e].x * a.scale) * p[e].x, (v[e].y * a.scale) * p[e].y);
+        c2r_phase(true, 3, x2);                                       // d vort/dy                         main.cpp:168
+        {
+            cf zy[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zy[e] = cf_make(v[e].x * a.scale, v[e].y * a.scale);
+            c2r_phase(true, 0, xn);                                   // d psi/dx                          main.cpp:214,225-227
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = cf_make(p[e].x - (v[e].x * a.scale) * zy[e].x, p[e].y - (v[e].y * a.scale) * zy[e].y);
+        }
+        const int tt = launder(t), wl = tt >> 6, ll = tt & 63;
+        if (a.src) {
+            const float2 *sp = reinterpret_cast<const float2 *>(a.src) + (size_t)xrow * M + tt;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float2 q = sp[e * 512]; v[e].x += q.x; v[e].y += q.y; }
+        }
+        rh_fwd<1>(v1, xbuf, tw, wq, wl, ll);                          // main.cpp:237 (y part)
+        RH_WAIT_ROW();
+        lds_barrier();
+#pragma unroll
+        for (int e = 4; e < 8; ++e) lds_wr(&xbuf[tt + 512 * (e - 4)], v[e]);       // W[k], k >= M/2, at k - M/2
+        lds_barrier();
+        cf tk[4], tm[4];                                              // T_h[k], T_h[M-k], k = t + 512 e < M/2
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = tt + 512 * e;
+            const cf wk = v[e];
+            if (e == 0 && tt == 0) { tk[0] = cf_make(wk.x + wk.y, 0.f); tm[0] = cf_make(wk.x - wk.y, 0.f); continue; }   // T[0], T[M]
+            const cf wm = lds_rd(&xbuf[M / 2 - k]);
+            const cf ev = cf_make(0.5f * (wk.x + wm.x), 0.5f * (wk.y - wm.y));
+            const cf od = cf_make(0.5f * (wk.y + wm.y), 0.5f * (wm.x - wk.x));
+            cf co = cmulc(od, wx);
+            switch (e) {
+            case 1: co = mul_w16<1, -1>(co); break; case 2: co = mul_w16<2, -1>(co); break; case 3: co = mul_w16<3, -1>(co); break;
+            default: break;
+            }
+            tk[e] = cadd(ev, co);
+            const cf d = csub(ev, co);
+            tm[e] = cf_make(d.x, -d.y);
+        }
+        const cf th = cf_make(v[4].x, -v[4].y);                       // thread 0: T[M/2] = conj W[M/2]
+        // the halves swap their spectra through the exchange buffers (natural index, M + 1 slots)
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int k = tt + 512 * e; lds_wr(&xbuf[k], tk[e]); lds_wr(&xbuf[M - k], tm[e]); }
+        if (tt == 0) lds_wr(&xbuf[M / 2], th);
+        lds_barrier();
+        if (valid) {
+            auto comb = [&](cf mine, cf other) { return h ? cmul(csub(other, mine), wb) : cadd(mine, other); };   // U_0 = T_0 + T_1 ; U_1 = W_nx^{x2} (T_0 - T_1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = tt + 512 * e;
+                st2<false>(const_cast<cf *>(row_ptr<false>(a.T, 0, xrow, k)), comb(tk[e], lds_rd(&xoth[k])));
+                st2<false>(const_cast<cf *>(row_ptr<false>(a.T, 0, xrow, M - k)), comb(tm[e], lds_rd(&xoth[M - k])));
+            }
+            if (tt == 0) *const_cast<cf *>(row_ptr<false>(a.T, 0, xrow, M / 2)) = comb(th, lds_rd(&xoth[M / 2]));
+        }
+    }
+}

@@ -237,7 +237,7 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
         if (const char *e = getenv("FB_PITCH_EXTRA")) c->P += 16 * atoi(e);   // tuning hook (disables the autotuner below)
         c->ngroups = 1; c->grp[0] = ColGroup{c->P, 0, 0};
         c->KA = c->P; c->KF = 0; c->katot = c->P;
-        Ptot = c->P + 64;                                  // room for the pitch candidates of autotune_pitch()
+        Ptot = c->P + 96;                                  // room for the pitch candidates of autotune_pitch()
     } else {
         c->katot = world * c->KA;
         c->ngroups = c->KF > 0 ? 2 : 1;
@@ -536,6 +536,18 @@ template <int V> static int launch_rowh(fb_ctx *c, const RowArgs &a)
     return FB_OK;
 }
 
+static int launch_rowh2(fb_ctx *c, const RowArgs &a)
+{
+    int grid = a.nx, cap = c->max_wg / 8;         // one 1024-thread workgroup per CU, each loops over x2
+    if (const char *e = getenv("FB_ROW_GRID")) { int v = atoi(e); if (v >= 64) cap = v; }
+    if (grid > cap) grid = cap;
+    int rc = set_max_lds(c, (const void *)k_rowh2, RowH2::LDS_BYTES);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rowh2, dim3(grid), dim3(1024), RowH2::LDS_BYTES, c->stream, a, (const cf *)c->d_tw_4096, (const cf *)c->d_tw_row3);
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
 template <int MODE> static int launch_row(fb_ctx *c, const RowArgs &a)
 {
     if (a.nx <= 0) return FB_OK;
@@ -661,15 +673,33 @@ static void finish_groups(fb_ctx *c)
 // backward strided pass of four fields: 4096^2: P = 2064 0.0955 ms, 2080 0.084 ms; 8192^2: P = 4112 0.393 ms,
 // 4128 0.586 ms).  So on large single-GPU grids the pitch is chosen by timing that pass for a few candidates.
 // Results do not depend on the pitch (pad columns are zero and every pass is linear).
+// 0: the model's x pass will be the three column kernels; 1 / 2: the single-pass k_col_full with nx = 4096 / 8192 (fb_col_full.h)
+static int full_pass_nsub(const fb_ctx *c)
+{
+    const char *fp = getenv("FB_FULL_PASS");
+    if (c->world != 1 || !c->nyq_frozen || ((c->ny / 2) % 8) != 0 || (fp && fp[0] == '0')) return 0;
+    if (c->nx == 4096) return 1;
+    if (c->nx == 8192 && c->rowh_v == 1) return 2;
+    return 0;
+}
+
 static int autotune_pitch(fb_ctx *c)
 {
     finish_groups(c);
     if (c->world != 1 || getenv("FB_PITCH_EXTRA") || getenv("FB_NO_PITCH_TUNE")) return FB_OK;
     if ((size_t)c->nx * c->P * sizeof(cf) < ((size_t)32 << 20)) return FB_OK;      // cache-resident grids: nothing to gain
-    const int P0 = c->P, NC = 4;
+    const int nsub = full_pass_nsub(c);
+    const int P0 = c->P, NC = nsub ? 5 : 4;
+    const size_t maxe = (size_t)c->nx * (P0 + 16 * (NC - 1));
+    // the probe is the pitch-sensitive kernel of the path the model will take: the backward strided sub-pass of one field, or
+    // k_col_full's PRIME launch (64-byte row segments of four derivative fields, rows P*8 bytes apart)
     cf *buf = nullptr;
-    if (hipMalloc((void **)&buf, (size_t)c->nx * (P0 + 16 * (NC - 1)) * sizeof(cf)) != hipSuccess) { hipGetLastError(); return FB_OK; }
-    hipMemsetAsync(buf, 0, (size_t)c->nx * (P0 + 16 * (NC - 1)) * sizeof(cf), c->stream);
+    if (hipMalloc((void **)&buf, maxe * (nsub ? 5 : 1) * sizeof(cf)) != hipSuccess) { hipGetLastError(); return FB_OK; }
+    hipMemsetAsync(buf, 0, maxe * (nsub ? 5 : 1) * sizeof(cf), c->stream);
+    if (nsub) {
+        const void *fn = nsub == 1 ? (const void *)k_col_full<4, 1> : (const void *)k_col_full<4, 2>;
+        if (set_max_lds(c, fn, CF_LDS_BYTES)) { hipFree(buf); return FB_OK; }
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f; int bestP = P0;
@@ -677,8 +707,18 @@ static int autotune_pitch(fb_ctx *c)
         ColGroup G = c->grp[0]; G.ncols = P0 + 16 * k;
         float tmin = 1e30f;
         for (int rep = 0; rep < 3; ++rep) {
+            int rc = FB_OK;
             hipEventRecord(e0, c->stream);
-            int rc = launch_col_strided<+1>(c, G, buf, 1, 0);
+            if (nsub) {
+                FullArgs a; memset(&a, 0, sizeof(a));
+                a.Zbase = buf; a.W4 = buf + maxe; a.fstride = (long)c->nx * G.ncols; a.P = G.ncols; a.ntiles = (c->ny / 2) / 8;
+                a.ntiles_run = a.ntiles + 1; a.nsub = nsub; a.stage = 4; a.coef = make_coef(c); a.tw256 = c->d_tw_256;
+                a.tw4096 = nsub == 1 ? c->d_tw_big : c->d_tw_4096; a.sub_rows = 4096;
+                const dim3 g(nsub * (a.ntiles + 1)), b(CF_THREADS);
+                if (nsub == 1) hipLaunchKernelGGL((k_col_full<4, 1>), g, b, CF_LDS_BYTES, c->stream, a);
+                else hipLaunchKernelGGL((k_col_full<4, 2>), g, b, CF_LDS_BYTES, c->stream, a);
+                if (hipGetLastError() != hipSuccess) rc = FB_EHIP;
+            } else rc = launch_col_strided<+1>(c, G, buf, 1, 0);
             hipEventRecord(e1, c->stream);
             hipEventSynchronize(e1);
             float ms = 0.f;
@@ -809,10 +849,10 @@ struct fb_model {
     float nu, dt;
     GroupBufs gb[2];
     bool phase_flow;                 // driven phase by phase (fb_slab_*): always the three-kernel column path
-    // single-pass x-transform path (fb_col_full.h): ZA/ZB/ACC then use that kernel's private layout and
-    // the frozen ky = ny/2 column of vort_c is kept in znyq[nx] (natural kx order)
+    // single-pass x-transform path (fb_col_full.h): ZA/ZB/ACC then use that kernel's private layout; nsub = nx/4096
+    // (2: the remaining radix-2 step of the x transform is fused into the row pass, k_rowh2)
     bool full;
-    cf *znyq;
+    int nsub;
     // hipGraph replay of one RK4 step (launch-bound small grids): captured lazily on a non-null stream,
     // dropped whenever something baked into the kernel arguments changes (source pointer, stream)
     bool use_graph, warmed;
@@ -835,7 +875,9 @@ static int model_create_impl(fb_model **out, fb_ctx *c, float nu, float dt, bool
     // single-pass x transform (fb_col_full.h) where it applies: one GPU, nx = 4096, frozen Nyquist column, whole
     // 8-column tiles.  0.177 ms per stage against 0.21 ms for the three column kernels; FB_FULL_PASS=0 keeps the latter.
     const char *fp = getenv("FB_FULL_PASS");
-    m->full = !phase_flow && c->world == 1 && c->nx == 4096 && c->nyq_frozen && ((c->ny / 2) % 8) == 0 && !(fp && fp[0] == '0');
+    (void)fp;
+    m->nsub = phase_flow ? 0 : full_pass_nsub(c);
+    m->full = m->nsub != 0;
     int rc = FB_OK;
     auto alloc0 = [&](cf **p, size_t elems) {              // zero-initialised device array (pad columns stay zero: every pass is linear)
         if (rc || elems == 0) return;
@@ -843,11 +885,10 @@ static int model_create_impl(fb_model **out, fb_ctx *c, float nu, float dt, bool
         if (hipMemsetAsync(*p, 0, elems * sizeof(cf), c->stream) != hipSuccess) rc = fail(FB_EHIP, "hipMemsetAsync failed");
     };
     if (m->full) {
-        alloc0(&m->znyq, (size_t)c->nx);
-        for (int st = 0; st < 4 && !rc; ++st) {
-            const void *fn = st == 0 ? (const void *)k_col_full<0> : st == 1 ? (const void *)k_col_full<1> : st == 2 ? (const void *)k_col_full<2> : (const void *)k_col_full<3>;
-            rc = set_max_lds(c, fn, CF_LDS_BYTES);
-        }
+        const void *fns[10] = {(const void *)k_col_full<0, 1>, (const void *)k_col_full<1, 1>, (const void *)k_col_full<2, 1>, (const void *)k_col_full<3, 1>,
+                               (const void *)k_col_full<4, 1>, (const void *)k_col_full<0, 2>, (const void *)k_col_full<1, 2>, (const void *)k_col_full<2, 2>,
+                               (const void *)k_col_full<3, 2>, (const void *)k_col_full<4, 2>};
+        for (int st = 0; st < 10 && !rc; ++st) rc = set_max_lds(c, fns[st], CF_LDS_BYTES);
     }
     for (int g = 0; g < c->ngroups; ++g) {
         const size_t n = grp_elems(c, c->grp[g]);
@@ -880,7 +921,6 @@ extern "C" int fb_model_destroy(fb_model *m)
         cf *arr[] = {B.ZA, B.ZB, B.ACC, B.w4_send, B.t_send};
         for (cf *p : arr) if (p) hipFree(p);
     }
-    if (m->znyq) hipFree(m->znyq);
     model_drop_graph(m);
     if (m->src) hipFree(m->src);
     for (auto p : m->nat) if (p) hipFree(p);
@@ -904,6 +944,7 @@ extern "C" int fb_model_info(fb_model *m, size_t *hbm, size_t *alg)
 static MidArgs mid_args(fb_model *m, int g, int stage);
 static int full_import_state(fb_model *m, cf *spec3);
 static int full_export_state(fb_model *m, cf *dst);
+static int launch_rowh2(fb_ctx *c, const RowArgs &a);
 
 extern "C" int fb_model_set_vort(fb_model *m, const float *d_vort)
 {
@@ -952,33 +993,18 @@ static MidArgs mid_args(fb_model *m, int g, int stage)
 }
 
 
-// copy the ky = col column of a 3-pass-layout spectral array to / from znyq[kx]
-template <bool EXTRACT>
-__global__ void k_nyq_col(cf *arr, cf *znyq, int nx, int P, int N1, int N2, int col)
-{
-    const int kx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (kx >= nx) return;
-    const size_t p = (size_t)(N2 * (kx % N1) + kx / N1) * P + col;
-    if (EXTRACT) znyq[kx] = arr[p]; else arr[p] = znyq[kx];
-}
+static int launch_col_full(fb_model *m, int stage);
 
-// full-path model: vort_c arrives in the 3-pass layout in `spec3` (clobbered): prime W4 through the
-// 3-pass kernels (all columns, including the frozen ky = ny/2 one), then move the state over
+// full-path model: vort_c arrives in the 3-pass layout in `spec3`: move it into k_col_full's layout (every column, the
+// frozen ky = ny/2 one included) and run the PRIME launch, which leaves the four derivative fields of every column in W4
 static int full_import_state(fb_model *m, cf *spec3)
 {
     fb_ctx *c = m->c;
-    const ColGroup &G = c->grp[0];
-    GroupBufs &B = m->gb[0];
-    int rc;
-    MidArgs a = mid_args(m, 0, -1);
-    if ((rc = state_convert(c, G, spec3, B.ACC, true))) return rc;     // ACC is free here: tile-major copy for the priming pass
-    a.Zbase = B.ACC;
-    if ((rc = launch_col_mid(c, a))) return rc;
-    if ((rc = launch_col_strided<+1>(c, G, B.w4_send, 4, (long)priv_elems(c)))) return rc;
-    hipLaunchKernelGGL((k_nyq_col<true>), dim3((c->nx + 255) / 256), dim3(256), 0, c->stream, spec3, m->znyq, c->nx, c->P, c->N1, c->N2, c->ny / 2);
     const int ntiles = (c->ny / 2) / 8;
-    hipLaunchKernelGGL((k_full_relayout<true>), dim3(c->max_wg), dim3(256), 0, c->stream, (const cf *)spec3, B.ZA, c->P, c->N1, c->N2, ntiles);
+    hipLaunchKernelGGL((k_full_relayout<true>), dim3(c->max_wg), dim3(256), 0, c->stream, (const cf *)spec3, m->gb[0].ZA, c->P, c->N1, c->N2, ntiles, m->nsub, c->hy);
     HIPCHK(hipGetLastError());
+    int rc = launch_col_full(m, 4);
+    if (rc) return rc;
     m->primed = 2;
     return FB_OK;
 }
@@ -989,12 +1015,12 @@ static int full_export_state(fb_model *m, cf *dst)
     fb_ctx *c = m->c;
     HIPCHK(hipMemsetAsync(dst, 0, priv_elems(c) * sizeof(cf), c->stream));
     const int ntiles = (c->ny / 2) / 8;
-    hipLaunchKernelGGL((k_full_relayout<false>), dim3(c->max_wg), dim3(256), 0, c->stream, (const cf *)m->gb[0].ZA, dst, c->P, c->N1, c->N2, ntiles);
-    hipLaunchKernelGGL((k_nyq_col<false>), dim3((c->nx + 255) / 256), dim3(256), 0, c->stream, dst, m->znyq, c->nx, c->P, c->N1, c->N2, c->ny / 2);
+    hipLaunchKernelGGL((k_full_relayout<false>), dim3(c->max_wg), dim3(256), 0, c->stream, (const cf *)m->gb[0].ZA, dst, c->P, c->N1, c->N2, ntiles, m->nsub, c->hy);
     HIPCHK(hipGetLastError());
     return FB_OK;
 }
 
+// stage 0..3: forward x transform of the tendency + RK update + derivatives; stage 4: PRIME (derivatives of vort_c only)
 static int launch_col_full(fb_model *m, int stage)
 {
     fb_ctx *c = m->c;
@@ -1002,16 +1028,22 @@ static int launch_col_full(fb_model *m, int stage)
     FullArgs a;
     a.Tin = B.t_recv; a.Zbase = B.ZA; a.Zcur = B.ZB; a.Acc = B.ACC; a.Zout = B.ZA; a.W4 = B.w4_send;
     a.fstride = (long)priv_elems(c); a.P = c->P; a.ntiles = (c->ny / 2) / 8; a.stage = stage; a.nu = m->nu; a.dt = m->dt;
-    a.ntiles_active = c->grp[0].nct_active * 2 < a.ntiles ? c->grp[0].nct_active * 2 : a.ntiles;
-    if (getenv("FB_FULL_NOSKIP")) a.ntiles_active = a.ntiles;
-    a.coef = make_coef(c); a.tw256 = c->d_tw_256; a.tw4096 = c->d_tw_big;
-    const dim3 g(a.ntiles), b(CF_THREADS);
+    a.nsub = m->nsub; a.sub_rows = 4096;
+    a.ntiles_run = c->grp[0].nct_active * 2 < a.ntiles ? c->grp[0].nct_active * 2 : a.ntiles;   // 16-column tiles -> 8-column tiles
+    if (getenv("FB_FULL_NOSKIP")) a.ntiles_run = a.ntiles;
+    if (stage == 4) a.ntiles_run = a.ntiles + 1;
+    a.coef = make_coef(c); a.tw256 = c->d_tw_256; a.tw4096 = m->nsub == 1 ? c->d_tw_big : c->d_tw_4096;
+    const dim3 g(m->nsub * (stage == 4 ? a.ntiles + 1 : a.ntiles)), b(CF_THREADS);
+#define FB_LAUNCH_FULL(ST) do { if (m->nsub == 1) hipLaunchKernelGGL((k_col_full<ST, 1>), g, b, CF_LDS_BYTES, c->stream, a); \
+                                else hipLaunchKernelGGL((k_col_full<ST, 2>), g, b, CF_LDS_BYTES, c->stream, a); } while (0)
     switch (stage) {
-    case 0: hipLaunchKernelGGL(k_col_full<0>, g, b, CF_LDS_BYTES, c->stream, a); break;
-    case 1: hipLaunchKernelGGL(k_col_full<1>, g, b, CF_LDS_BYTES, c->stream, a); break;
-    case 2: hipLaunchKernelGGL(k_col_full<2>, g, b, CF_LDS_BYTES, c->stream, a); break;
-    default: hipLaunchKernelGGL(k_col_full<3>, g, b, CF_LDS_BYTES, c->stream, a); break;
+    case 0: FB_LAUNCH_FULL(0); break;
+    case 1: FB_LAUNCH_FULL(1); break;
+    case 2: FB_LAUNCH_FULL(2); break;
+    case 3: FB_LAUNCH_FULL(3); break;
+    default: FB_LAUNCH_FULL(4); break;
     }
+#undef FB_LAUNCH_FULL
     HIPCHK(hipGetLastError());
     return FB_OK;
 }
@@ -1084,9 +1116,12 @@ static int model_step_impl(fb_model *m, int nsteps, StepProf *prof)
     for (int s = 0; s < nsteps; ++s) {
         for (int k = 0; k < 4; ++k) {
             // row pass on the derivative fields left by the previous stage (or the priming pass) ...
-            const RowArgs a = fused_row_args(m, 0, c->XL);
+            RowArgs a = fused_row_args(m, 0, c->XL);
             PROF_BEGIN(1);
-            if ((rc = launch_row<ROW_FUSED>(c, a))) return rc;
+            if (m->full && m->nsub == 2) {                // one workgroup per x2 produces the rows x2 and x2 + 4096 (k_rowh2)
+                a.nx = 4096; a.sub_rows = 4096; a.tw_x = c->d_tw_big;
+                if ((rc = launch_rowh2(c, a))) return rc;
+            } else if ((rc = launch_row<ROW_FUSED>(c, a))) return rc;
             PROF_END(1);
             if (m->full) {                        // two launches per stage: row pass, single-pass x transform
                 PROF_BEGIN(3);
