@@ -213,21 +213,28 @@ template <int DIR> struct Bfly<16, DIR> {
 //                       p = h + 4 s (s < NP), q < 8, R1 = n/8; lanes with h >= R1 idle if R1 < 4
 //  A2B: LA -> LB (radix-R1 in registers over m, twiddle W_n^{g p}, LDS exchange, radix-8 over g)
 //  B2A: LB -> LA (radix-8 over q, twiddle, LDS exchange, radix-R1 over p)
-//  LDS per wave: R1 * WT_PSTR complex.  Only the calling wave touches its region; DS
+//  LDS per wave: min(R1, 8) * WT_PSTR complex: for n = 128 (R1 = 16) the exchange runs in two rounds of 8 p-rows
+//  (p = h + 4 s: rows 0-7 belong to s = 0,1 and rows 8-15 to s = 2,3), which halves the per-wave LDS (9 KB instead of 18 KB)
+//  and doubles the waves a CU can hold.  Only the calling wave touches its region; DS
 //  instructions of one wave execute in order, so no barrier is required between phases.
 // ============================================================================================
 #define WT_PSTR 144   /* [p][g(8)][col(16)] + 16 complex pad: keeps the LB accesses conflict-free */
 
+#ifndef FB_MID128_WAVES
+#define FB_MID128_WAVES 2     /* k_col_mid<128> (nx = 16384): 256 registers, two workgroups per CU */
+#endif
 template <int n> struct WaveTile {
     static constexpr int R1 = n / 8;
     static constexpr int NP = R1 >= 4 ? R1 / 4 : 1;
     static constexpr int NLB = NP * 8;        // complex per lane in LB
     static constexpr int NLA = n / 8;         // float4 per lane in LA
-    static constexpr int LDS_CF = R1 * WT_PSTR;
+    static constexpr int ROUNDS = R1 > 8 ? R1 / 8 : 1;      // exchange rounds
+    static constexpr int PR = R1 / ROUNDS;                  // p-rows per round
+    static constexpr int LDS_CF = PR * WT_PSTR;
     static constexpr bool TM = R1 >= 4;       // state arrays in the tile-major layout (fb_kernels.h)
     static FB_DEV bool lb_active(int lane) { return R1 >= 4 || (lane >> 4) < R1; }
     // register-allocation target of the fused middle kernel (waves per SIMD)
-    static constexpr int MID_MIN_WAVES = n >= 128 ? 1 : (n >= 64 ? 2 : (n >= 32 ? 4 : 2));   // n < 32: row-layout state path, tiny grids
+    static constexpr int MID_MIN_WAVES = n >= 128 ? FB_MID128_WAVES : (n >= 64 ? 2 : (n >= 32 ? 4 : 2));   // n < 32: row-layout state path, tiny grids
 };
 
 template <int n, int DIR>
@@ -240,29 +247,34 @@ FB_DEV void wave_fft_A2B(const float4 *in /*[n/8]*/, cf *out /*[NLB]*/, cf *lds,
     for (int m = 0; m < R1; ++m) { a0[m] = cf_make(in[m].x, in[m].y); a1[m] = cf_make(in[m].z, in[m].w); }
     Bfly<R1, DIR>::run(a0);
     Bfly<R1, DIR>::run(a1);
+    constexpr int ROUNDS = WaveTile<n>::ROUNDS, PR = WaveTile<n>::PR;
 #pragma unroll
-    for (int p = 0; p < R1; ++p) {
-        if (p > 0) {
-            cf w = tw_n[g * p];
-            a0[p] = cmul_dir<DIR>(a0[p], w);
-            a1[p] = cmul_dir<DIR>(a1[p], w);
+    for (int r = 0; r < ROUNDS; ++r) {
+#pragma unroll
+        for (int pp = 0; pp < PR; ++pp) {
+            const int p = r * PR + pp;
+            if (p > 0) {
+                cf w = tw_n[g * p];
+                a0[p] = cmul_dir<DIR>(a0[p], w);
+                a1[p] = cmul_dir<DIR>(a1[p], w);
+            }
+            *reinterpret_cast<float4 *>(&lds[pp * WT_PSTR + g * 16 + 2 * cp]) = make_float4(a0[p].x, a0[p].y, a1[p].x, a1[p].y);
         }
-        *reinterpret_cast<float4 *>(&lds[p * WT_PSTR + g * 16 + 2 * cp]) = make_float4(a0[p].x, a0[p].y, a1[p].x, a1[p].y);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (WaveTile<n>::lb_active(lane)) {
+        __builtin_amdgcn_wave_barrier();
+        if (WaveTile<n>::lb_active(lane)) {
 #pragma unroll
-        for (int s = 0; s < NP; ++s) {
-            const int p = h + 4 * s;
-            cf v[8];
+            for (int s = r * (NP / ROUNDS); s < (r + 1) * (NP / ROUNDS); ++s) {
+                const int pp = h + 4 * s - r * PR;              // row of p = h + 4 s within this round
+                cf v[8];
 #pragma unroll
-            for (int gg = 0; gg < 8; ++gg) v[gg] = lds[p * WT_PSTR + gg * 16 + c];
-            Bfly<8, DIR>::run(v);
+                for (int gg = 0; gg < 8; ++gg) v[gg] = lds[pp * WT_PSTR + gg * 16 + c];
+                Bfly<8, DIR>::run(v);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) out[s * 8 + q] = v[q];
+                for (int q = 0; q < 8; ++q) out[s * 8 + q] = v[q];
+            }
         }
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
 }
 
 template <int n, int DIR>
@@ -270,28 +282,33 @@ FB_DEV void wave_fft_B2A(const cf *in /*[NLB]*/, float4 *out /*[n/8]*/, cf *lds,
 {
     constexpr int R1 = WaveTile<n>::R1, NP = WaveTile<n>::NP;
     const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
-    if (WaveTile<n>::lb_active(lane)) {
-#pragma unroll
-        for (int s = 0; s < NP; ++s) {
-            const int p = h + 4 * s;
-            cf v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = in[s * 8 + q];
-            Bfly<8, DIR>::run(v);
-#pragma unroll
-            for (int gg = 0; gg < 8; ++gg) {
-                cf x = v[gg];
-                if (gg > 0) x = cmul_dir<DIR>(x, tw_n[p * gg]);
-                lds[p * WT_PSTR + gg * 16 + c] = x;
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
+    constexpr int ROUNDS = WaveTile<n>::ROUNDS, PR = WaveTile<n>::PR;
     cf a0[R1], a1[R1];
 #pragma unroll
-    for (int p = 0; p < R1; ++p) {
-        float4 t = *reinterpret_cast<const float4 *>(&lds[p * WT_PSTR + g * 16 + 2 * cp]);
-        a0[p] = cf_make(t.x, t.y); a1[p] = cf_make(t.z, t.w);
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (WaveTile<n>::lb_active(lane)) {
+#pragma unroll
+            for (int s = r * (NP / ROUNDS); s < (r + 1) * (NP / ROUNDS); ++s) {
+                const int p = h + 4 * s, pp = p - r * PR;
+                cf v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = in[s * 8 + q];
+                Bfly<8, DIR>::run(v);
+#pragma unroll
+                for (int gg = 0; gg < 8; ++gg) {
+                    cf x = v[gg];
+                    if (gg > 0) x = cmul_dir<DIR>(x, tw_n[p * gg]);
+                    lds[pp * WT_PSTR + gg * 16 + c] = x;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pp = 0; pp < PR; ++pp) {
+            float4 t = *reinterpret_cast<const float4 *>(&lds[pp * WT_PSTR + g * 16 + 2 * cp]);
+            a0[r * PR + pp] = cf_make(t.x, t.y); a1[r * PR + pp] = cf_make(t.z, t.w);
+        }
+        if (r + 1 < ROUNDS) __builtin_amdgcn_wave_barrier();
     }
     Bfly<R1, DIR>::run(a0);
     Bfly<R1, DIR>::run(a1);

@@ -600,14 +600,12 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
 {
     using W = WaveTile<n>;
     __shared__ __attribute__((aligned(16))) cf smem[4 * W::LDS_CF + n + 4 * n];
-    __shared__ double s_kx2[4 * n];
-    __shared__ float s_gx[4 * n];
+    __shared__ float s_gx[4 * n];                    // (double)gradx_coe^2 is formed from it on the fly: exactly the table entry, 4 n doubles of LDS less
     const int wv = threadIdx.x >> 6;
     cf *lds = smem + wv * W::LDS_CF;
     cf *twn = smem + 4 * W::LDS_CF;                  // W_n^k, whole workgroup
     cf *twb = twn + n + wv * n;                      // W_nx^{b cb} of this wave's tile, b = 0..n-1
-    double *kx2t = s_kx2 + wv * n;                   // (double)gradx_coe^2 at kx = cb + N1 d, d = 0..n-1
-    float *gxt = s_gx + wv * n;
+    float *gxt = s_gx + wv * n;                      // gradx_coe at kx = cb + N1 d, d = 0..n-1
     for (int i = threadIdx.x; i < n; i += 256) twn[i] = a.tw_n[i];
     __syncthreads();
     const int ntc = a.nct, ntc_all = a.P >> 4;
@@ -636,7 +634,6 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
             if (n >= 64 || d < n) {
                 twb[d] = a.tw_big[d * cb];
                 gxt[d] = a.coef.gx[cb + a.N1 * d];
-                kx2t[d] = a.coef.kx2[cb + a.N1 * d];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -655,7 +652,7 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
                 // one RK update of element e; dvortdt_c += lvort_c * NU ; rk = dealiase(dvortdt_c)   main.cpp:148,240-243,296
                 auto update = [&](int e, cf z0, cf zcur, cf ac, cf &acc, cf &znew) {
                     const int d = h + 4 * (e >> 3) + W::R1 * (e & 7), ikx = cb + a.N1 * d;
-                    const float lap = (float)(-(kx2t[d] + ky2));
+                    const float lap = (float)(-((double)gxt[d] * (double)gxt[d] + ky2));     // fftwfop.cpp:42,45
                     const float msk = coef_mask(a.coef, ikx, ky);
                     const cf zc = a.stage == 0 ? z0 : zcur;
                     cf k = cf_make((th[e].x + (zc.x * lap) * a.nu) * msk, (th[e].y + (zc.y * lap) * a.nu) * msk);
@@ -771,7 +768,7 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {                 // main.cpp:179, fftwfop.cpp:112-117
                             const int e = s * 8 + q, d = hf + 4 * s + W::R1 * q, ikx = cb + a.N1 * d;
-                            const float li = (ikx == 0 && ky == 0) ? 1.0f : (float)(-(kx2t[d] + ky2));
+                            const float li = (ikx == 0 && ky == 0) ? 1.0f : (float)(-((double)gxt[d] * (double)gxt[d] + ky2));
                             zn[e] = (ky < a.coef.hy) ? cf_make(zn[e].x / li, zn[e].y / li) : cf_make(0.f, 0.f);
                         }
                 }
