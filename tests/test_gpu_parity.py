@@ -609,3 +609,42 @@ def test_rowh_matches_stockham_row_kernel(O, R, nx, ny):
     mo.set_source(src)
     mo.step(3)
     assert R.rel_l2(outs[""], mo.vort()) < 1e-5
+
+
+def test_single_pass_8192_matches_three_kernel_path_and_oracle(O, R):
+    """nx = ny = 8192: k_col_full on the two wavenumber sub-sequences kx = 2 k2 + k1 with the radix-2 x step fused into the row
+    pass (k_rowh2) -- the default there -- against the three-kernel x pass (FB_FULL_PASS=0) and the oracle, on a field with energy at
+    every wavenumber (never dealiased: frozen tiles and the ky = ny/2 column carry state) plus a vorticity source; vort, spectrum, u."""
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, numpy as np; sys.path[:0]=[%r, %r]\n"
+        "import xlab_fftbarotropic_amd as X\n"
+        "n = 8192; rng = np.random.default_rng(31)\n"
+        "v0 = (rng.standard_normal((n, n)) * 1e-4).astype(np.float32) + X.make_field('gaussian', n)\n"
+        "src = (rng.standard_normal((n, n)) * 1e-9).astype(np.float32)\n"
+        "m = X.Model(n, n, dt=0.375); m.set_vort(v0); back = m.vort().cpu().numpy()[::8, ::8]; m.set_source(src); m.step(2)\n"
+        "psi, u, v = m.diag()\n"
+        "np.savez(sys.argv[1], back=back, vort=m.vort().cpu().numpy()[::4, ::4], spec=np.ascontiguousarray(m.spectrum().cpu().numpy()[:, ::5]), u=u.cpu().numpy()[::8, ::8])\n"
+    ) % (os.path.dirname(HERE), HERE)
+    with tempfile.TemporaryDirectory() as d:
+        outs = {}
+        for flag in ("1", "0"):
+            a = os.path.join(d, "o%s.npz" % flag)
+            subprocess.check_call([sys.executable, "-c", code, a], env=dict(os.environ, FB_FULL_PASS=flag))
+            outs[flag] = dict(np.load(a))
+    n = 8192
+    rng = np.random.default_rng(31)
+    v0 = (rng.standard_normal((n, n)) * 1e-4).astype(np.float32) + O.make_field("gaussian", n)
+    src = (rng.standard_normal((n, n)) * 1e-9).astype(np.float32)
+    assert R.rel_l2(outs["1"]["back"], v0[::8, ::8]) < 1e-6                       # set_vort / vort() through the single-pass state layout
+    for k in ("vort", "spec", "u"):
+        assert R.rel_l2(outs["1"][k].view(np.float32), outs["0"][k].view(np.float32)) < 2e-6, k
+    mo = O.Model(n, n, dt=0.375)
+    mo.set_vort(v0)
+    mo.set_source(src)
+    mo.step(2)
+    assert R.rel_l2(outs["1"]["vort"], mo.vort()[::4, ::4]) < 1e-5
+    assert R.rel_l2(outs["1"]["spec"].view(np.float32), np.ascontiguousarray(mo.spectrum()[:, ::5]).view(np.float32)) < 1e-5
+    assert R.rel_l2(outs["1"]["u"], mo.diag()[1][::8, ::8]) < 1e-5

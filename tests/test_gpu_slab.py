@@ -130,7 +130,7 @@ def _invariants(v0, v1, with_source=False):
 
 def test_config4_8192_gaussian_on_4_ranks_full_size():
     """BASELINE configs[3]: 8192 x 8192 gaussian vortex, dt = 3*1024/8192 s, ky slabs over 4 ranks -- full size.
-    One RK4 step: the 4-rank engine path against the fused single-GPU path (bit for bit), the oracle
+    One RK4 step: the 4-rank engine path against the single-GPU run of the same kernels (bit for bit), the default single-GPU path, the oracle
     (main-shallow-water.cpp:277-338 == main.cpp:259-317 for a zero source) and the invariants."""
     import oracle_py as O
     import ref_numpy as R
@@ -138,22 +138,33 @@ def test_config4_8192_gaussian_on_4_ranks_full_size():
     n, world, dt = 8192, 4, 3.0 * 1024 / 8192
     v0 = X.make_field("gaussian", n)
     assert np.array_equal(v0[::64, ::64], O.make_field("gaussian", n)[::64, ::64])
-    ref = X.Model(n, n, dt=dt)
+    ref = X.Model(n, n, dt=dt)                                                        # default single-GPU path: k_rowh2 + k_col_full
     ref.set_vort(v0)
     s0 = ref.spectrum()[0, 0].item()
     ref.step(1)
     assert ref.spectrum()[0, 0].item() == s0                                          # mean vorticity conserved exactly
+    want_default = ref.vort().cpu().numpy()
+    del ref
+    os.environ["FB_FULL_PASS"] = "0"                                                  # the three-kernel x pass: the kernels the ranks run
+    try:
+        ref = X.Model(n, n, dt=dt)
+    finally:
+        os.environ.pop("FB_FULL_PASS", None)
+    ref.set_vort(v0)
+    ref.step(1)
     want = ref.vort().cpu().numpy()
     del ref
     back, got, plan = slab_run(n, world, 1, v0, dt)
     assert plan == (4, 4, 976, 64)                                                    # 16 MB per peer and field: fully pipelined
     assert R.rel_l2(back, v0) < 1e-6
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert R.rel_l2(got, want_default) < 2e-6                                         # same maths, another factorisation of the x transform
     _invariants(v0, got)
     mo = O.Model(n, n, dt=dt)
     mo.set_vort(v0)
     mo.step(1)
     assert R.rel_l2(got, mo.vort()) < 1e-5                                            # north-star bar, stated for 1000 steps
+    assert R.rel_l2(want_default, mo.vort()) < 1e-5
 
 
 def test_config5_16384_source_forced_on_8_ranks_full_size():
