@@ -92,8 +92,17 @@ def cpu_baseline(n, dt, kind, steps):
     the faithful figure -- the reference is single-threaded (Makefile:2, no threads anywhere) -- plus the same code on all
     cores (OpenMP) and the small configs, as SURVEY.md 8(d) asks.  Bounded: about 20-30 s in all."""
     nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share, how = nproc, "every core the process may run on"
+    try:                                                # a container's CPU quota, not the host's core count, is what this process can use
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            share, how = max(1, -(-int(q) // int(per))), "the cgroup CPU quota"
+    except (OSError, ValueError):
+        pass
+    if share == nproc and nproc > 16:
+        share, how = 16, "the GPU box's CPU share for one GPU (16), nproc reports the whole host"
     v1, _ = cpu_leg(n, dt, kind, steps, 1)
-    vall, used = cpu_leg(n, dt, kind, max(steps, 5), nproc)
+    vall, used = cpu_leg(n, dt, kind, max(steps, 5), share)
     small = {}
     for ns, ks in ((256, 40), (1024, 10)):
         if ns < n:
@@ -103,7 +112,7 @@ def cpu_baseline(n, dt, kind, steps):
             "sample": "%dx%d %s, %d RK4 steps after 1 warm-up, oracle/liboracle.so (own FFT, reference loop structure), 1 thread"
                       % (n, n, kind, steps),
             "all_cores": {"value": vall, "unit": "steps/s", "cores": used, "nproc": nproc,
-                          "sample": "same workload, %d steps, OpenMP over the oracle's loops and FFT batches" % max(steps, 5)},
+                          "sample": "same workload, %d steps, OpenMP over the oracle's loops and FFT batches; threads = %s" % (max(steps, 5), how)},
             "other_configs_steps_per_s": small}
 
 
