@@ -198,7 +198,20 @@ def test_invert_pres_against_oracle_pipeline(tmp_path):
         pres = O.c2r(ops.invertLaplacian(lp.view(np.complex64)), n) / g
         pres = pres - pres.ravel()[3 + n * 5]
         got = np.fromfile(str(tmp_path / "output" / ("pres_step_%d.bin" % step)), dtype="<f4").reshape(n, n)
-        assert R.rel_l2(got, pres) < 1e-4, step          # two chained 2-D FFT round trips of an ill-scaled field
+        # the same pipeline in fp64 numpy (tables of the reference's float32 values): how far is ANY float32 evaluation from it?
+        gx, gy, lap, lapi, mask = (t.astype(np.float64) for t in R.tables(n, n, 6e5, 6e5))
+        p64 = np.fft.rfft2(psi.astype(np.float64))
+        ikx, iky = 1j * gx[:, None], 1j * gy[None, :]
+        i2 = lambda s_: np.fft.irfft2(s_ * mask, s=(n, n))
+        curv64 = i2(ikx * ikx * p64) * i2(iky * iky * p64) - i2(ikx * iky * p64) ** 2
+        pres64 = np.fft.irfft2((lap * p64 * 1e-5 + 2.0 * np.fft.rfft2(curv64)) / lapi, s=(n, n))
+        pres64 = pres64 - pres64.ravel()[3 + n * 5]
+        e_gpu_oracle, e_oracle_64, e_gpu_64 = R.rel_l2(got, pres), R.rel_l2(pres, pres64), R.rel_l2(got, pres64)
+        print("invert_pres step %d: GPU vs oracle %.2e, oracle vs fp64 %.2e, GPU vs fp64 %.2e" % (step, e_gpu_oracle, e_oracle_64, e_gpu_64))
+        # measured on MI355X: GPU vs oracle 7e-7 .. 1e-6, oracle vs fp64 4e-7 .. 5e-7, GPU vs fp64 8e-7 .. 1e-6 -- the pipeline
+        # (second derivatives, their product, a Laplacian inversion, one reference point subtracted from every value) does not
+        # amplify float32 rounding beyond the bar of the RK4 path, so the same bar applies (round 1 asserted 1e-4 here)
+        assert e_gpu_oracle < 1e-5 and e_gpu_64 < 1e-5 and e_oracle_64 < 1e-5, step
 
 
 def test_fifo_producer_stream_matches_reference_and_oracle():
