@@ -158,7 +158,7 @@ def main():
         model = slab.SlabModel(n, n, dt=dt, rank=rank, world=world)
         slab_info = {"rows_per_rank": model.XL, "active_cols_per_rank": model.KA, "frozen_cols_per_rank": model.KF,
                      "field_groups": model.field_groups, "row_chunks": model.row_chunks,
-                     "transport": "rccl" if args.backend == "nccl" else "gloo callback (rehearsal)"}
+                     "transport": model.transport}
         v0_local = torch.from_numpy(slab.local_rows(X.make_field(kind, n), rank, world)).cuda()
 
         def reset_state():

@@ -106,13 +106,26 @@ class EngineSlab:
         self.XL, self.KA, self.KF, self.kyA0, self.kyF0, self.field_groups, self.row_chunks = [x.value for x in v]
         assert world == 1 or (self.XL, self.KA, self.KF) == slab_geometry(nx, ny, world)      # one rank: one group of all columns at the engine's pitch
         self._cb = None
+        self.transport = "none"
         if world > 1:
             if transport == "rccl":
-                self._connect_rccl()
+                try:
+                    self._connect_rccl()
+                    self.transport = "rccl (engine: grouped ncclSend/ncclRecv)"
+                except B.FftBaroError as e:
+                    # LOUD second choice, never silent: the same bytes through torch.distributed's own point-to-point calls
+                    # (RCCL as well when the process group is nccl) behind the callback transport.  Reported in bench.py's line.
+                    import sys
+                    print("EngineSlab rank %d: engine RCCL transport unavailable (%s); using torch.distributed point-to-point behind "
+                          "the callback transport" % (rank, e), file=sys.stderr)
+                    self._connect_gloo()
+                    self.transport = "torch.distributed %s point-to-point (callback)" % dist.get_backend()
             elif transport == "gloo":
                 self._connect_gloo()
+                self.transport = "torch.distributed %s point-to-point (callback)" % dist.get_backend()
             elif isinstance(transport, int):
                 B.check(self.L.fb_slab_connect_local(self._h, C.c_void_p(transport)))
+                self.transport = "local (threads of one process)"
             else:
                 raise B.FftBaroError("EngineSlab: world > 1 needs transport='rccl', 'gloo' or a local hub handle")
 
