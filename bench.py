@@ -66,6 +66,8 @@ def pmc_traffic(prof, kernel, launches_per_step=4):
         if k.startswith(pre) and k.endswith(suf) if suf else k.startswith(pre):
             if kernel == "k_row_fused" and d.get("launches", 0) < 8:          # set_vort / get_vort launches of the non-fused modes
                 continue
+            if kernel == "k_col_full" and k.startswith("k_col_full<4"):       # the PRIME launch after set_vort is not a stage
+                continue
             tot += d["hbm_bytes_per_launch_corrected"] * d["launches"]
             cnt += d["launches"]
     return tot / cnt if cnt else None
@@ -104,7 +106,7 @@ def cpu_baseline(n, dt, kind, steps):
     v1, _ = cpu_leg(n, dt, kind, steps, 1)
     vall, used = cpu_leg(n, dt, kind, max(steps, 5), share)
     small = {}
-    for ns, ks in ((256, 40), (1024, 10)):
+    for ns, ks in ((256, 40), (1024, 20)):
         if ns < n:
             v, _ = cpu_leg(ns, 3.0, "elliptic", ks, 1)
             small["%dx%d elliptic, 1 core" % (ns, ns)] = v
