@@ -1,8 +1,3 @@
-// compat/fieldio.hpp -- the reference's declarations (fieldio.hpp:5-6); the definitions are in lib/libfieldio.so
-// and libfftbaro.so (csrc/fb_fieldio.cpp), exported with the reference's mangled names.
-#include <cstddef>
-#ifndef FIELDIO_H
-#define FIELDIO_H
-void writeField(const char *filename, float *data, size_t len);
-void readField(const char *filename, float *data, size_t len);
-#endif
+/* compat/fieldio.hpp -- lets a translation unit that says `#include "fieldio.hpp"` (main.cpp:18) build against the MI355X
+ * engine with -I<repo>/xlab-fftbarotropic_amd/host/compat -I<repo>/include and -lfieldio (or -lfftbaro). */
+#include "fieldio_fb.h"

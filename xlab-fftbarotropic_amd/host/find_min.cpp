@@ -1,72 +1,81 @@
-// find_min.cpp -- post-processor of the reference's pressure pipeline (find_min.cpp:67-101):
-// for every file name on stdin, the 30 smallest values of the field and their grid positions, one
-// "<ix> <iy> <value %.5e>" line each on stdout, in the order the reference's selection leaves them.
-// Host only (an O(N^2) scan of a field on disk); the field comes through readField (lib/libfieldio.so).
-// The reference fixes the grid at compile time (configuration.hpp:18-21); here --npts / --xpts / --ypts.
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
+// find_min.cpp -- last stage of the reference's pressure pipeline (find_min.cpp:67-101):
+// for every file name on stdin, the 30 smallest values of that field with their grid positions, one
+// "<ix> <iy> <value %.5e>" line each on stdout.  Host only: an O(N^2) scan of a field read through readField
+// (lib/libfieldio.so).  The reference fixes the grid at compile time (configuration.hpp:18-21); here --npts / --xpts / --ypts.
+//
+// The ORDER of the 30 lines is part of the behaviour (downstream scripts take line 1 as "the" minimum position only after
+// sorting; the raw order is what the reference prints): the reference keeps the first 30 values, then lets every smaller
+// value evict the currently largest kept one (find_min.cpp:42-64), so the output is in eviction-slot order, unsorted.
+// `Kept` below is that selection; tests/test_host_cpp.py pins the output line for line, ties included, to the reference's
+// own find_min.cpp built into oracle/_ref.
 #include <getopt.h>
 
-#include "compat/fieldio.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
 
-static void trim(char *str)                      // find_min.cpp:22-30: strips trailing newlines
-{
-    size_t n = strlen(str);
-    while (n > 0 && str[n - 1] == '\n') str[--n] = '\0';
-}
+#include "fieldio.hpp"
 
-static size_t find_max_pos(const float *data, size_t sz)      // find_min.cpp:32-40
-{
-    size_t max_i = 0;
-    for (size_t i = 1; i < sz; ++i)
-        if (data[i] > data[max_i]) max_i = i;
-    return max_i;
-}
+namespace {
 
-// find_min.cpp:42-64: keep the first result_sz values, then replace the current maximum of the kept set by every
-// smaller value met; the output order is the replacement order (not sorted), which the test pins
-static void find_min_n(const float *data, size_t data_sz, float *result, size_t *result_pos, size_t result_sz)
-{
-    if (result_sz > data_sz) { fprintf(stderr, "Data size is %zu, but you request %zu numbers.\n", data_sz, result_sz); return; }
-    for (size_t i = 0; i < result_sz; ++i) { result[i] = data[i]; result_pos[i] = i; }
-    size_t max_i = find_max_pos(result, result_sz);
-    for (size_t i = result_sz; i < data_sz; ++i) {
-        if (data[i] < result[max_i]) {
-            result[max_i] = data[i];
-            result_pos[max_i] = i;
-            max_i = find_max_pos(result, result_sz);
+struct Kept {
+    std::vector<float> value;
+    std::vector<size_t> where;
+    size_t worst = 0;                                  // slot of the largest kept value: the FIRST such slot, as a strict '>' scan finds it
+
+    explicit Kept(size_t n) : value(n), where(n) {}
+    void rescan()
+    {
+        worst = 0;
+        for (size_t s = 1; s < value.size(); ++s)
+            if (value[s] > value[worst]) worst = s;
+    }
+    void select(const float *field, size_t count)
+    {
+        const size_t n = value.size();
+        for (size_t s = 0; s < n; ++s) { value[s] = field[s]; where[s] = s; }
+        rescan();
+        for (size_t i = n; i < count; ++i) {
+            if (!(field[i] < value[worst])) continue;  // strictly smaller values only: ties keep the earlier point
+            value[worst] = field[i];
+            where[worst] = i;
+            rescan();
         }
     }
-}
+};
+
+}  // namespace
 
 int main(int argc, char *argv[])
 {
-    int xpts = 768, ypts = 768;                   // configuration.hpp:18
-    static const struct option lo[] = {{"npts", required_argument, 0, 1}, {"xpts", required_argument, 0, 2},
-                                       {"ypts", required_argument, 0, 3}, {0, 0, 0, 0}};
-    for (int c; (c = getopt_long(argc, argv, "", lo, nullptr)) != -1;) {
-        if (c == 1) xpts = ypts = atoi(optarg);
-        else if (c == 2) xpts = atoi(optarg);
-        else if (c == 3) ypts = atoi(optarg);
-        else { fprintf(stderr, "usage: find_min.out [--npts N | --xpts NX --ypts NY] < list-of-files\n"); return 2; }
+    long xpts = 768, ypts = 768;                       // configuration.hpp:18
+    const option longopts[] = {{"npts", required_argument, nullptr, 'n'}, {"xpts", required_argument, nullptr, 'x'},
+                               {"ypts", required_argument, nullptr, 'y'}, {nullptr, 0, nullptr, 0}};
+    for (int c; (c = getopt_long(argc, argv, "", longopts, nullptr)) != -1;) {
+        switch (c) {
+        case 'n': xpts = ypts = atol(optarg); break;
+        case 'x': xpts = atol(optarg); break;
+        case 'y': ypts = atol(optarg); break;
+        default: fprintf(stderr, "usage: find_min.out [--npts N | --xpts NX --ypts NY] < list-of-files\n"); return 2;
+        }
     }
     if (xpts < 1 || ypts < 1) { fprintf(stderr, "find_min: bad grid size\n"); return 2; }
-    const size_t grids = (size_t)xpts * ypts, min_n = 30;
+    const size_t grids = (size_t)xpts * (size_t)ypts, wanted = 30;
     fprintf(stderr, "Entering find_min program.\n");
-    float *data = (float *)malloc(sizeof(float) * grids), *mn = (float *)malloc(sizeof(float) * min_n);
-    size_t *pos = (size_t *)malloc(sizeof(size_t) * min_n);
-    if (!data || !mn || !pos) { fprintf(stderr, "find_min: out of memory\n"); return 1; }
-    char filename[1024];
-    while (fgets(filename, sizeof filename, stdin) != NULL) {
-        trim(filename);
-        readField(filename, data, grids);
-        fprintf(stderr, "File %s read.\n", filename);
-        find_min_n(data, grids, mn, pos, min_n);
-        for (size_t i = 0; i < min_n && i < grids; ++i)
-            fprintf(stdout, "%zu %zu %.5e\n", pos[i] / (size_t)ypts, pos[i] % (size_t)ypts, mn[i]);    // find_min.cpp:84-88
+    if (wanted > grids) { fprintf(stderr, "Data size is %zu, but you request %zu numbers.\n", grids, wanted); return 1; }
+    std::vector<float> field(grids);
+    Kept kept(wanted);
+    char line[1024];
+    while (fgets(line, sizeof line, stdin)) {
+        std::string name(line);
+        while (!name.empty() && name.back() == '\n') name.pop_back();       // find_min.cpp:22-30
+        readField(name.c_str(), field.data(), grids);
+        fprintf(stderr, "File %s read.\n", name.c_str());
+        kept.select(field.data(), grids);
+        for (size_t s = 0; s < wanted; ++s)                                 // find_min.cpp:84-88
+            printf("%zu %zu %.5e\n", kept.where[s] / (size_t)ypts, kept.where[s] % (size_t)ypts, kept.value[s]);
     }
     fprintf(stderr, "find_min program ends. Congrats!\n");
-    free(data); free(mn); free(pos);
     return 0;
 }
