@@ -246,7 +246,8 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
          *ZO = reinterpret_cast<char *>(a.Zout) + ubase_s;
     const double ky2a = a.coef.ky2[ky0], ky2b = a.coef.ky2[ky0 + 1];
     const float gya = a.coef.gy[ky0], gyb = a.coef.gy[ky0 + 1];
-    const bool pada = ky0 >= a.coef.hy, padb = ky0 + 1 >= a.coef.hy;                    // PRIME's last tile: columns beyond ny/2 are zero padding
+    constexpr bool PRIME_ = STAGE == 4;
+    const bool pada = PRIME_ && ky0 >= a.coef.hy, padb = PRIME_ && ky0 + 1 >= a.coef.hy;      // PRIME's last tile: columns beyond ny/2 are zero padding
     constexpr int stage = STAGE;
     const float nu = a.nu, dt = a.dt, hdt = (stage == 2) ? a.dt : a.dt / 2.0f;
     // The state arrays move in batches of two k3: the loads of batch b+1 are issued before the stores of batch b,
