@@ -107,8 +107,8 @@ def test_slab_geometry_plan_and_world1():
     assert slab.slab_geometry(8192, 8192, 4) == (2048, 976, 64)
     assert slab.slab_geometry(16384, 16384, 8) == (2048, 976, 64)
     assert slab.slab_geometry(4096, 4096, 8) == (512, 256, 16)
-    assert slab.stage_plan(8192, 8192, 4) == (4, 4) and slab.stage_plan(16384, 16384, 8) == (4, 4)
-    assert slab.stage_plan(4096, 4096, 8) == (2, 1) and slab.stage_plan(4096, 4096, 1) == (1, 1)
+    assert slab.stage_plan(8192, 8192, 4) == (4, 1) and slab.stage_plan(16384, 16384, 8) == (4, 2)
+    assert slab.stage_plan(4096, 4096, 2) == (2, 1) and slab.stage_plan(4096, 4096, 8) == (1, 1) and slab.stage_plan(4096, 4096, 1) == (1, 1)
     assert L.fb_slab_plan(1000, 1000, 2, None, None, None, 0) == 0             # unsupported grid
     n = 32
     rng = np.random.default_rng(0)

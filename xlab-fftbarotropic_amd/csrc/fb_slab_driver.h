@@ -12,8 +12,8 @@
 //   S: row pass of row chunk 0 | chunk 1 | ...                                  C: all-to-all(tendency chunk 0) | chunk 1 ...
 //   S: forward x pass + RK update + derivatives (needs every row)
 // so the links are busy from the end of the first sub-pass to the arrival of the last tendency chunk, and only the
-// forward pass, the first sub-pass and the first row chunk are exposed.  The granularity adapts to the message size
-// (fb_slab_plan): below ~2 MB per peer and operation RCCL's per-operation latency costs more than the overlap gains.
+// forward pass, the first sub-pass and the first row chunk are exposed.  The granularity follows the local work a piece hides
+// (fb_slab_plan): a piece that hides less than a collective's latency is not cut off.
 #pragma once
 #include "fb_transport.h"
 
@@ -40,9 +40,13 @@ static void slab_plan(int nx, int ny, int world, int *nfg, int *nch)
     int jmax, KA, KF;
     slab_split(ny, (double)(float)((double)dxw * dxw + (double)dyw * dyw), world, jmax, KA, KF);
     const long XL = nx / world;
-    const double field_mb = (double)XL * KA * 8.0 / (1 << 20);       // one field, one peer
-    int fg = world == 1 ? 1 : (field_mb >= 2.0 ? 4 : (2 * field_mb >= 2.0 ? 2 : 1));
-    int ch = world == 1 ? 1 : (field_mb >= 8.0 ? 4 : (field_mb >= 4.0 ? 2 : 1));
+    // Pipelining a transpose against the pass that feeds it hides that pass's time, minus one more collective's latency per
+    // extra piece (tens of microseconds for a grouped RCCL send/recv).  So the derivative exchange is cut by fields only where one
+    // field's backward sub-pass (2 * nx * KA * 8 bytes at ~5 TB/s) is worth an operation, and the tendency exchange by row chunks
+    // only where half the row pass (5 * XL * (ny/2+1) * 8 bytes at ~4 TB/s) is.
+    const double bwd_us = 2.0 * nx * KA * 8.0 / 5e6, row_us = 5.0 * XL * (ny / 2 + 1) * 8.0 / 4e6;
+    int fg = world == 1 ? 1 : (bwd_us >= 20.0 ? 4 : (bwd_us >= 10.0 ? 2 : 1));
+    int ch = world == 1 ? 1 : (row_us >= 100.0 ? 2 : 1);
     if (const char *e = getenv("FB_SLAB_FIELD_GROUPS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) fg = v; }
     if (const char *e = getenv("FB_SLAB_ROW_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 8) ch = v; }
     while (ch > 1 && ((XL / ch) & 1 || XL % ch)) ch >>= 1;          // chunks are whole row pairs

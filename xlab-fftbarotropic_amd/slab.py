@@ -46,9 +46,9 @@ def slab_geometry(nx, ny, world):
 def stage_plan(nx, ny, world):
     """(field groups, row chunks) of one RK stage's two transposes -- mirrors slab_plan() in csrc/fb_slab_driver.h."""
     xl, ka, _ = slab_geometry(nx, ny, world)
-    field_mb = xl * ka * 8.0 / (1 << 20)
-    fg = 1 if world == 1 else (4 if field_mb >= 2.0 else (2 if 2 * field_mb >= 2.0 else 1))
-    ch = 1 if world == 1 else (4 if field_mb >= 8.0 else (2 if field_mb >= 4.0 else 1))
+    bwd_us, row_us = 2.0 * nx * ka * 8.0 / 5e6, 5.0 * xl * (ny // 2 + 1) * 8.0 / 4e6      # one field's backward sub-pass, the row pass
+    fg = 1 if world == 1 else (4 if bwd_us >= 20.0 else (2 if bwd_us >= 10.0 else 1))
+    ch = 1 if world == 1 else (2 if row_us >= 100.0 else 1)
     while ch > 1 and ((xl // ch) & 1 or xl % ch):
         ch >>= 1
     return fg, ch
