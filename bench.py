@@ -204,6 +204,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    local_ms = None
+    if world > 1:
+        # how much of that is local work: the same schedule with a transport that moves nothing (fields are garbage, timing is not)
+        m0 = slab.EngineSlab(n, n, dt=dt, rank=rank, world=world, transport="null", dist=dist)
+        m0.set_vort_local(v0_local)
+        m0.step(max(1, min(W, 3)))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        m0.step(K)
+        torch.cuda.synchronize()
+        tl = torch.tensor([time.perf_counter() - t1], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        local_ms = 1e3 * float(tl.item()) / K
+        m0.close()
+
     ms_per_step = 1e3 * elapsed / K
     steps_per_s = K / elapsed
     alg_bytes = 320.0 * n * n
@@ -219,6 +234,7 @@ def main():
     }
     if slab_info:
         out["config"]["slab"] = slab_info
+        out["local_passes_ms_per_step"] = local_ms          # the step with exchanges that move nothing: what is left is the links
 
     if rank == 0 and world == 1:
         # per-kernel HIP-event timing over a second pass of the same K steps (events on the launch stream)

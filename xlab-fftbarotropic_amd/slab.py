@@ -90,6 +90,7 @@ class EngineSlab:
        "rccl"  -- ncclCommInitRank with an id that rank 0 creates and torch.distributed broadcasts (the product path)
        "gloo"  -- torch.distributed point-to-point behind the callback transport (ranks may share one GPU: rehearsal)
        hub     -- an integer handle from `local_hub(world)`: all ranks are threads of this process (rehearsal)
+       "null"  -- exchanges move nothing (wrong fields, right timing of the local passes)
        None    -- world == 1"""
 
     def __init__(self, nx, ny=None, Lx=600000.0, Ly=600000.0, nu=6.5, dt=3.0, rank=0, world=1, transport=None, dist=None):
@@ -126,6 +127,12 @@ class EngineSlab:
             elif isinstance(transport, int):
                 B.check(self.L.fb_slab_connect_local(self._h, C.c_void_p(transport)))
                 self.transport = "local (threads of one process)"
+            elif transport == "null":
+                # moves nothing: the fields are garbage, the local passes and the schedule are the real ones -- bench.py times it
+                # to report how much of a multi-GPU step is local work
+                self._cb = self.B.ALLTOALL_FN(lambda user, send, recv, stride, offset, count, stream: 0)
+                B.check(self.L.fb_slab_connect_callback(self._h, self._cb, None))
+                self.transport = "null (timing of the local passes only)"
             else:
                 raise B.FftBaroError("EngineSlab: world > 1 needs transport='rccl', 'gloo' or a local hub handle")
 
