@@ -345,10 +345,11 @@ def test_single_pass_x_transform_with_long_rows(X, O, R):
     assert np.isfinite(s.view(np.float32)).all()
 
 
-def test_row8_matches_stockham_row_kernel(O, R):
-    """fb_row8.h (default at ny = 4096) against the Stockham row kernel (FB_NO_ROW8=1): same maths, different
-    factorisation and physical-space ordering -- with a vorticity source, whose gather follows that ordering.
-    Child processes: the switch is read when the context is created."""
+def test_row_kernels_4096_agree(O, R):
+    """The three fused row kernels for ny = 4096 -- k_rowq (default: one real row per 4-wave workgroup as a 2048-point complex
+    transform), k_row8 (FB_ROWQ=0: two rows per 8-wave workgroup as one 4096-point transform) and the Stockham kernel (FB_NO_ROW8=1)
+    -- are the same maths with different factorisations and physical-space orderings; with a vorticity source, whose gather follows
+    that ordering.  Child processes: the switches are read when the context is created."""
     import subprocess
     import sys
     import tempfile
@@ -363,16 +364,17 @@ def test_row8_matches_stockham_row_kernel(O, R):
     ) % (os.path.dirname(HERE), HERE)
     with tempfile.TemporaryDirectory() as d:
         outs = {}
-        for flag in ("", "1"):
+        for tag, extra in (("rowq", {}), ("row8", {"FB_ROWQ": "0"}), ("stockham", {"FB_NO_ROW8": "1"})):
             env = dict(os.environ)
             env.pop("FB_NO_ROW8", None)
-            if flag:
-                env["FB_NO_ROW8"] = flag
-            a = os.path.join(d, "v%s.npy" % flag)
+            env.pop("FB_ROWQ", None)
+            env.update(extra)
+            a = os.path.join(d, "v%s.npy" % tag)
             subprocess.check_call([sys.executable, "-c", code, a], env=env)
-            outs[flag] = np.load(a)
-    assert np.isfinite(outs[""]).all()
-    assert R.rel_l2(outs[""], outs["1"]) < 2e-6
+            outs[tag] = np.load(a)
+    assert np.isfinite(outs["rowq"]).all()
+    assert R.rel_l2(outs["rowq"], outs["stockham"]) < 2e-6 and R.rel_l2(outs["row8"], outs["stockham"]) < 2e-6
+    assert not np.array_equal(outs["rowq"], outs["row8"])              # (they really are different kernels)
     # and against the oracle (CPU restatement of main.cpp:146-317)
     rng = np.random.default_rng(5)
     v0 = rng.standard_normal((512, 4096)).astype(np.float32) * 1e-4
@@ -381,7 +383,7 @@ def test_row8_matches_stockham_row_kernel(O, R):
     mo.set_vort(v0)
     mo.set_source(src)
     mo.step(3)
-    assert R.rel_l2(outs[""], mo.vort()) < 1e-5
+    assert R.rel_l2(outs["rowq"], mo.vort()) < 1e-5 and R.rel_l2(outs["row8"], mo.vort()) < 1e-5
 
 
 def test_graph_replay_matches_eager(X, torch):
@@ -466,7 +468,7 @@ def test_config3_1000_steps_stay_physical(X):
 # ---------------------------------------------------------------------------------------------------
 def test_config3_1000_steps_tolerance_4096(X, R):
     """North star: vorticity within 1e-5 relative L2 of the CPU path after 1000 RK4 steps (main.cpp:259-317), at the headline grid,
-    on the default path (k_row8 + k_col_full).  The CPU side is the committed fixture tests/golden/oracle_4096_step1000.npz: the
+    on the default path (k_rowq + k_col_full).  The CPU side is the committed fixture tests/golden/oracle_4096_step1000.npz: the
     oracle (C restatement of main.cpp:146-317) run for 1000 steps in the build container by tests/golden/make_long_fixtures.py,
     every 16th point in x and y plus the full-field L2 norm and sum at steps 100, 500 and 1000."""
     G = np.load(os.path.join(HERE, "golden", "oracle_4096_step1000.npz"))
@@ -504,7 +506,7 @@ def _noise_run(env, steps, tmpdir, tag):
     import subprocess
     import sys
     e = dict(os.environ)
-    for k in ("FB_FULL_PASS", "FB_FULL_NOSKIP", "FB_NO_COLUMN_SKIP", "FB_NO_ROW8"):
+    for k in ("FB_FULL_PASS", "FB_FULL_NOSKIP", "FB_NO_COLUMN_SKIP", "FB_NO_ROW8", "FB_ROWQ"):
         e.pop(k, None)
     e.update(env)
     out = os.path.join(tmpdir, tag + ".npz")

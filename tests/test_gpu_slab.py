@@ -101,7 +101,7 @@ def test_engine_slab_matches_fused_path(world, n, steps, env):
 
 
 def test_engine_slab_4096_uses_the_headline_row_kernel():
-    """ny = 4096 on 2 ranks: the slab row pass is k_row8 too (slab-blocked addressing); the column side is the
+    """ny = 4096 on 2 ranks: the slab row pass is k_rowq too (slab-blocked addressing); the column side is the
     three-kernel path on both sides (FB_FULL_PASS=0 for the single-GPU reference) -> bit-identical."""
     import subprocess
     import sys
@@ -112,7 +112,7 @@ def test_engine_slab_4096_uses_the_headline_row_kernel():
     v0 = (rng.standard_normal((nx, ny)) * 1e-4).astype(np.float32)
     src = (rng.standard_normal((nx, ny)) * 1e-9).astype(np.float32)
     _, got, _ = slab_run(nx, world, steps, v0, 0.75, src=src, ny=ny)
-    ref = X.Model(nx, ny, dt=0.75)                      # nx = 512: three-kernel column path, k_row8 row pass
+    ref = X.Model(nx, ny, dt=0.75)                      # nx = 512: three-kernel column path, k_rowq row pass
     ref.set_vort(v0)
     ref.set_source(src)
     ref.step(steps)

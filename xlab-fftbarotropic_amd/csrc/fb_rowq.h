@@ -1,0 +1,250 @@
+// fb_rowq.h -- fused row pass for ny = 4096 with ONE real row per 256-thread workgroup: four contexts per CU.
+//
+// k_row8 (fb_row8.h) packs two real rows into one 4096-point complex transform run by 512 threads: two workgroups per CU, every
+// phase fenced by eight-wave barriers.  Here one real row of N = 4096 points is one complex transform of M = 2048 points
+// (even/odd packing, exactly as in fb_rowh.h), run by FOUR waves: 35 KB of LDS per workgroup, four workgroups per CU, so that
+// four rows in different phases share a CU and a barrier only ever stops four waves.  M = 2048 = 8 x 4 x 8 x 8:
+//     thread = (wave w 0..3, lane = 8 l_hi + l_lo), 8 registers
+//     stage 0: radix 8 over the registers (positions t + 256 e)              twiddle W_2048^{p t}
+//     G exchange (registers <-> wave index), the only workgroup-wide one: afterwards wave w' holds p = w' and p = w' + 4
+//     stage 1: two radix-4 butterflies over the old wave index              twiddle W_256^{q lane}
+//     A exchange (registers <-> l_hi, wave-private), stage 2: radix 8       twiddle W_64^{r l_lo}
+//     B exchange (registers <-> l_lo, wave-private), stage 3: radix 8
+// backward (decimation in frequency) as listed, forward the transposed sequence.  The backward output is digit-reversed:
+//     j = (w + 4 (l_hi >> 2)) + 8 (l_hi & 3) + 32 l_lo + 256 e
+// which never matters (the Jacobian is pointwise; vort_src is permuted once into this order).
+// Same arithmetic as k_row8 / k_row<4096, ROW_FUSED> up to rounding order (main.cpp:154-237, y part).
+#pragma once
+#include "fb_rowh.h"
+
+struct RowQ {
+    static constexpr int M = 2048, N = 4096, T = 256;
+    static constexpr int SLICE = Row8::SLICE;                  // per-wave slice of the exchange buffer (A/B exchanges)
+    static constexpr int XBUF = 4 * SLICE;                      // four wave slices; the G exchange uses 8 * 64 of each
+    static constexpr int STG = M + 2;
+    static constexpr int TW2 = 64;
+    static constexpr size_t LDS_BYTES = (size_t)(XBUF + STG + TW2) * sizeof(cf);
+};
+struct RowQTw { cf w0[7], w1[3]; const cf *w2; };              // W_2048^{p t}, W_256^{q lane} in registers; W_64^{r l_lo} in LDS
+
+// G exchange.  Element p of the stage-0 output of wave w goes to wave p & 3 as register (q = w, h = p >> 2); it travels through
+// the RECEIVING wave's slice, [p & 3][(p >> 2) * 4 + w][lane], so that after the barrier every wave reads its own slice only and
+// may go on to the wave-private exchanges without another barrier.
+FB_DEV void rq_xch_group_bwd(cf *v, cf *xbuf, int w, int l)
+{
+    lds_barrier();                                    // every wave is done with its slice
+#pragma unroll
+    for (int p = 0; p < 8; ++p) lds_wr(&xbuf[(p & 3) * RowQ::SLICE + ((p >> 2) * 4 + w) * 64 + l], v[p]);
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = lds_rd(&xbuf[w * RowQ::SLICE + j * 64 + l]);         // j = 4 h + q
+}
+// forward direction: the inverse permutation (register (q, h) of wave w is element p = w + 4 h of wave q)
+FB_DEV void rq_xch_group_fwd(cf *v, cf *xbuf, int w, int l)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds_wr(&xbuf[w * RowQ::SLICE + j * 64 + l], v[j]);          // own slice: no barrier needed before
+    lds_barrier();
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v[p] = lds_rd(&xbuf[(p & 3) * RowQ::SLICE + ((p >> 2) * 4 + w) * 64 + l]);
+    lds_barrier();                                    // the slices are free again
+}
+
+FB_DEV void rq_bwd(cf *v, cf *xbuf, const RowQTw &tw, int w, int l)
+{
+    const int l_hi = l >> 3, l_lo = l & 7;
+    cf *slice = xbuf + w * RowQ::SLICE;
+    Bfly<8, +1>::run(v);
+#pragma unroll
+    for (int p = 1; p < 8; ++p) v[p] = cmulc(v[p], tw.w0[p - 1]);
+    rq_xch_group_bwd(v, xbuf, w, l);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        fft4<+1>(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) v[4 * h + q] = cmulc(v[4 * h + q], tw.w1[q - 1]);
+    }
+    r8_xch_wave<true>(v, slice, l_hi, l_lo);
+    Bfly<8, +1>::run(v);
+#pragma unroll
+    for (int p = 1; p < 8; ++p) v[p] = cmulc(v[p], lds_rd(&tw.w2[p * 8 + l_lo]));
+    r8_xch_wave<false>(v, slice, l_hi, l_lo);
+    Bfly<8, +1>::run(v);
+}
+
+FB_DEV void rq_fwd(cf *v, cf *xbuf, const RowQTw &tw, int w, int l)
+{
+    const int l_hi = l >> 3, l_lo = l & 7;
+    cf *slice = xbuf + w * RowQ::SLICE;
+    Bfly<8, -1>::run(v);
+    r8_xch_wave<false>(v, slice, l_hi, l_lo);
+#pragma unroll
+    for (int p = 1; p < 8; ++p) v[p] = cmul(v[p], lds_rd(&tw.w2[p * 8 + l_lo]));
+    Bfly<8, -1>::run(v);
+    r8_xch_wave<true>(v, slice, l_hi, l_lo);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q) v[4 * h + q] = cmul(v[4 * h + q], tw.w1[q - 1]);
+        fft4<-1>(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+    }
+    rq_xch_group_fwd(v, xbuf, w, l);
+#pragma unroll
+    for (int p = 1; p < 8; ++p) v[p] = cmul(v[p], tw.w0[p - 1]);
+    Bfly<8, -1>::run(v);
+}
+
+template <bool SLAB>
+FB_DEV void rq_dma_issue(cf *stg, int t, const RowView &view, int field, int row)
+{
+    constexpr int M = RowQ::M;
+    const int w = t >> 6, lane = t & 63;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                     // 16 chunks of 1 KiB, 4 per wave
+        const int ch = w + c * 4, k = ch * 128 + lane * 2;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(view, field, row, k), rh_to_lds(stg + ch * 128), 16, 0, 0);
+    }
+    rh_lds_ptr nyq = rh_to_lds(stg + M);              // X[M]: one dword per lane (lanes 0, 1)
+    const float *src = reinterpret_cast<const float *>(row_ptr<SLAB>(view, field, row, M)) + (t & 1);
+    if (t < 2) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src, nyq, 4, 0, 0);
+}
+
+FB_DEV void rq_ext(cf *v, int t, const cf *stg, cf wx /* exp(+2 pi i t/N) */)
+{
+    constexpr int M = RowQ::M;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = t + 256 * e;
+        cf a = lds_rd(&stg[k]), b = lds_rd(&stg[M - k]);
+        if (e == 0 && t == 0) { a.y = 0.f; b.y = 0.f; }                               // k = 0: X[0] and X[M] count as real (SURVEY note N2)
+        const cf ev = cf_make(a.x + b.x, a.y - b.y);
+        cf d = cmul(cf_make(a.x - b.x, a.y + b.y), wx);
+        switch (e) {                                                                   // e^{2 pi i 256 e/4096} = e^{2 pi i e/16}
+        case 1: d = mul_w16<1, +1>(d); break; case 2: d = mul_w16<2, +1>(d); break; case 3: d = mul_w16<3, +1>(d); break;
+        case 4: d = mul_w16<4, +1>(d); break; case 5: d = mul_w16<5, +1>(d); break; case 6: d = mul_w16<6, +1>(d); break;
+        case 7: d = mul_w16<7, +1>(d); break; default: break;
+        }
+        v[e] = cadd_ib(ev, d);
+    }
+}
+
+// physical-space index of (thread t, register e)
+FB_DEV int rq_phys(int t, int e)
+{
+    const int w = t >> 6, l = t & 63, l_hi = l >> 3, l_lo = l & 7;
+    return (w + 4 * (l_hi >> 2)) + 8 * (l_hi & 3) + 32 * l_lo + 256 * e;
+}
+
+// vort_src [x][y] -> float2 (y = 2j, 2j+1) at [x][e][t], j = rq_phys(t, e)
+__global__ void __launch_bounds__(256) k_rowq_permute_src(const float *__restrict__ in, float *__restrict__ out, int nrows)
+{
+    constexpr int M = RowQ::M;
+    const size_t total = (size_t)nrows * M;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx / M), r = (int)(idx - (size_t)x * M);
+        const int t = r & 255, e = r >> 8;
+        reinterpret_cast<float2 *>(out)[idx] = reinterpret_cast<const float2 *>(in)[(size_t)x * M + rq_phys(t, e)];
+    }
+}
+
+template <bool SLAB>
+__global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const cf *__restrict__ root2048 /* W_2048^j */, const cf *__restrict__ rootN /* W_4096^j */)
+{
+    constexpr int M = RowQ::M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *xbuf = reinterpret_cast<cf *>(smem_raw);
+    cf *stg = xbuf + RowQ::XBUF;
+    const int t = threadIdx.x, l = t & 63;
+    RowQTw tw;
+#pragma unroll
+    for (int p = 1; p < 8; ++p) tw.w0[p - 1] = root2048[p * t];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) tw.w1[q - 1] = root2048[8 * q * l];                   // W_256^{q l} = W_2048^{8 q l}
+    cf *tw2 = stg + RowQ::STG;
+    if (t < 64) tw2[t] = root2048[32 * (t & 7) * (t >> 3)];                           // W_64^{p l_lo} = W_2048^{32 p l_lo} at [p][l_lo]
+    tw.w2 = tw2;
+    cf wx;
+    { const cf r = rootN[t]; wx = cf_make(r.x, -r.y); }                               // exp(+2 pi i t/4096)
+#pragma unroll
+    for (int p = 0; p < 7; ++p) asm volatile("" :: "v"(tw.w0[p]));                    // land the table loads here, not behind a prefetch
+    asm volatile("" :: "v"(tw.w1[0]), "v"(tw.w1[1]), "v"(tw.w1[2]), "v"(wx));
+    __syncthreads();
+
+    const int iters = (a.nx + gridDim.x - 1) / gridDim.x;
+    auto row_of = [&](int it, bool &valid) { const int r = it * gridDim.x + blockIdx.x; valid = r < a.nx; return a.x0 + (valid ? r : 0); };
+    if (iters > 0) {
+        bool vld; const int x = row_of(0, vld);
+        rq_dma_issue<SLAB>(stg, t, a.M, 0, x);
+        RH_WAIT_ROW();
+    }
+    for (int it = 0; it < iters; ++it) {
+        bool valid;
+        const int x = row_of(it, valid);                              // an invalid workgroup recomputes row 0, stores nothing
+        bool vn = false;
+        const int xn = (it + 1 < iters) ? row_of(it + 1, vn) : -1;
+        cf v[8], p[8];
+        auto c2r_phase = [&](bool wait, int next_field, int next_row) {
+            const int tp = launder(t);
+            if (wait) RH_WAIT_ROW();
+            lds_barrier();
+            rq_ext(v, tp, stg, wx);
+            lds_barrier();
+            if (next_row >= 0) rq_dma_issue<SLAB>(stg, tp, a.M, next_field, next_row);
+            rq_bwd(v, xbuf, tw, tp >> 6, tp & 63);
+        };
+        c2r_phase(false, 2, x);                                       // d vort/dx                         main.cpp:154
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] = cf_make(v[e].x * a.scale, v[e].y * a.scale);
+        c2r_phase(true, 1, x);                                        // d psi/dy: -u * dvortdx = (c2r * scale) * dvortdx   main.cpp:200-201,225
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] = cf_make((v[e].x * a.scale) * p[e].x, (v[e].y * a.scale) * p[e].y);
+        c2r_phase(true, 3, x);                                        // d vort/dy                         main.cpp:168
+        {
+            cf zy[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zy[e] = cf_make(v[e].x * a.scale, v[e].y * a.scale);
+            c2r_phase(true, 0, xn);                                   // d psi/dx; the next row's first field travels meanwhile
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = cf_make(p[e].x - (v[e].x * a.scale) * zy[e].x, p[e].y - (v[e].y * a.scale) * zy[e].y);   // main.cpp:214,225-227
+        }
+        const int tt = launder(t);
+        if (a.src) {                                                  // + vort_src (permuted order)
+            const float2 *sp = reinterpret_cast<const float2 *>(a.src) + (size_t)x * M + tt;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float2 q = sp[e * 256]; v[e].x += q.x; v[e].y += q.y; }
+        }
+        rq_fwd(v, xbuf, tw, tt >> 6, tt & 63);                        // main.cpp:237 (y part)
+        RH_WAIT_ROW();                                                // the next row's first field has landed
+        lds_barrier();
+#pragma unroll
+        for (int e = 4; e < 8; ++e) lds_wr(&xbuf[tt + 256 * (e - 4)], v[e]);          // W[k], k >= M/2, at k - M/2
+        lds_barrier();
+        if (valid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = tt + 256 * e;                           // 0 <= k < M/2
+                const cf wk = v[e];
+                if (k == 0) {                                         // T[0] = Re W0 + Im W0 ; T[M] = Re W0 - Im W0
+                    if (row_keep<SLAB>(a.T, a.t_frozen, 0)) *const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x, 0)) = cf_make(wk.x + wk.y, 0.f);
+                    if (row_keep<SLAB>(a.T, a.t_frozen, M)) *const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x, M)) = cf_make(wk.x - wk.y, 0.f);
+                    continue;
+                }
+                const cf wm = lds_rd(&xbuf[M / 2 - k]);
+                const cf ev = cf_make(0.5f * (wk.x + wm.x), 0.5f * (wk.y - wm.y));
+                const cf od = cf_make(0.5f * (wk.y + wm.y), 0.5f * (wm.x - wk.x));
+                cf co = cmulc(od, wx);
+                switch (e) {
+                case 1: co = mul_w16<1, -1>(co); break; case 2: co = mul_w16<2, -1>(co); break; case 3: co = mul_w16<3, -1>(co); break;
+                default: break;
+                }
+                if (row_keep<SLAB>(a.T, a.t_frozen, k)) st2<false>(const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x, k)), cadd(ev, co));
+                const cf tm = csub(ev, co);
+                if (row_keep<SLAB>(a.T, a.t_frozen, M - k)) st2<false>(const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x, M - k)), cf_make(tm.x, -tm.y));
+            }
+            if (tt == 0 && row_keep<SLAB>(a.T, a.t_frozen, M / 2)) {
+                const cf wh = v[4];
+                *const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x, M / 2)) = cf_make(wh.x, -wh.y);
+            }
+        }
+    }
+}

@@ -17,6 +17,11 @@
 #include "fb_row3.h"
 #include "fb_row8.h"
 #include "fb_rowh.h"
+#include "fb_rowq.h"
+
+#ifndef FB_ROWQ_DEFAULT
+#define FB_ROWQ_DEFAULT 1     /* ny = 4096 row pass: 1 = k_rowq (one row per 256-thread workgroup, four per CU), 0 = k_row8 (two rows per 512-thread workgroup) */
+#endif
 
 // --------------------------------------------------------------------------------------------
 // errors
@@ -89,6 +94,8 @@ struct fb_ctx {
     bool use_row8;              // fused row pass of ny = 4096 through k_row8 (FB_NO_ROW8=1: the Stockham kernel)
     int rowh_v;                 // fused row pass of ny = 8192 (1) / 16384 (2) through k_rowh (FB_NO_ROWH=1: 0 = the Stockham kernel)
     cf *d_tw_4096;              // W_4096^j for k_rowh's sub-transforms
+    bool use_rowq;              // fused row pass of ny = 4096 through k_rowq (one real row per 4-wave workgroup) instead of k_row8
+    cf *d_tw_2048;              // W_2048^j for k_rowq
     int pace_strided;           // pace the strided sub-pass's accesses (fields much larger than the caches)
     int col_chunks;             // x pass of a stage is issued in this many column chunks ...
     int col_streams;            // ... round-robin over this many streams, so that one chunk's kernel tails are filled by the next chunk
@@ -274,6 +281,8 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
     c->use_row8 = ny == 4096 && !getenv("FB_NO_ROW8");
     c->rowh_v = (ny == 8192 || ny == 16384) && !getenv("FB_NO_ROWH") ? ny / 8192 : 0;
     if (c->rowh_v && (rc = upload(&c->d_tw_4096, make_root_table(4096)))) { fb_destroy(c); return rc; }
+    { const char *e = getenv("FB_ROWQ"); c->use_rowq = ny == 4096 && !getenv("FB_NO_ROW8") && (e ? e[0] != '0' : FB_ROWQ_DEFAULT); }
+    if (c->use_rowq && (rc = upload(&c->d_tw_2048, make_root_table(2048)))) { fb_destroy(c); return rc; }
     hipDeviceProp_t prop;
     if (hipGetDevice(&c->dev) != hipSuccess || hipGetDeviceProperties(&prop, c->dev) != hipSuccess) {
         fb_destroy(c); return fail(FB_EHIP, "fb_create: cannot query the device");
@@ -287,7 +296,7 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
 extern "C" int fb_destroy(fb_ctx *c)
 {
     if (!c) return FB_OK;
-    void *tabs[] = {c->d_gx, c->d_kx2, c->d_gy, c->d_ky2, c->d_tw_n1, c->d_tw_n2, c->d_tw_big, c->d_tw_row_bwd, c->d_tw_row_fwd, c->d_tw_256, c->d_tw_row3, c->d_tw_4096};
+    void *tabs[] = {c->d_gx, c->d_kx2, c->d_gy, c->d_ky2, c->d_tw_n1, c->d_tw_n2, c->d_tw_big, c->d_tw_row_bwd, c->d_tw_row_fwd, c->d_tw_256, c->d_tw_row3, c->d_tw_4096, c->d_tw_2048};
     for (void *t : tabs) if (t) hipFree(t);
     if (c->d_scratch) hipFree(c->d_scratch);
     for (int i = 0; i < 3; ++i) { if (c->aux[i]) hipStreamDestroy(c->aux[i]); if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]); }
@@ -536,6 +545,20 @@ template <int V> static int launch_rowh(fb_ctx *c, const RowArgs &a)
     return FB_OK;
 }
 
+static int launch_rowq(fb_ctx *c, const RowArgs &a)
+{
+    // one workgroup per row, four resident per CU: measured 0.076-0.078 ms per launch at 4096^2 against 0.081-0.084 with a persistent
+    // grid of 1024 looping over rows (the dispatcher's refill keeps the four contexts of a CU out of step; the prologue is cheap)
+    int grid = a.nx;
+    if (const char *e = getenv("FB_ROW_GRID")) { int v = atoi(e); if (v >= 64 && v < grid) grid = v; }
+    auto kern = c->world > 1 ? k_rowq<true> : k_rowq<false>;
+    int rc = set_max_lds(c, (const void *)kern, RowQ::LDS_BYTES);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), RowQ::LDS_BYTES, c->stream, a, (const cf *)c->d_tw_2048, (const cf *)c->d_tw_row3);
+    HIPCHK(hipGetLastError());
+    return FB_OK;
+}
+
 static int launch_rowh2(fb_ctx *c, const RowArgs &a)
 {
     int grid = a.nx, cap = c->max_wg / 8;         // one 1024-thread workgroup per CU, each loops over x2
@@ -551,6 +574,7 @@ static int launch_rowh2(fb_ctx *c, const RowArgs &a)
 template <int MODE> static int launch_row(fb_ctx *c, const RowArgs &a)
 {
     if (a.nx <= 0) return FB_OK;
+    if (MODE == ROW_FUSED && c->use_rowq) return launch_rowq(c, a);
     if (MODE == ROW_FUSED && c->use_row8 && a.nx >= 2) return launch_row8(c, a);
     if (MODE == ROW_FUSED && c->rowh_v == 1) return launch_rowh<1>(c, a);
     if (MODE == ROW_FUSED && c->rowh_v == 2) return launch_rowh<2>(c, a);
@@ -968,6 +992,11 @@ extern "C" int fb_model_set_source(fb_model *m, const float *d_src)
     const size_t n = (size_t)c->XL * c->ny * sizeof(float);       // the caller's local rows
     if (!d_src) { if (m->src) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(m->src); m->src = nullptr; } return FB_OK; }
     if (!m->src && hipMalloc((void **)&m->src, n) != hipSuccess) return fail(FB_ENOMEM, "source allocation failed");
+    if (c->use_rowq) {                                            // k_rowq reads vort_src in its own physical-space order
+        hipLaunchKernelGGL(k_rowq_permute_src, dim3(grid_for(c, (size_t)c->XL * c->ny / 2)), dim3(256), 0, c->stream, d_src, m->src, c->XL);
+        HIPCHK(hipGetLastError());
+        return FB_OK;
+    }
     if (c->rowh_v) {                                              // k_rowh reads vort_src in its own physical-space order
         const size_t pairs = (size_t)c->XL * c->ny / 2;
         if (c->rowh_v == 1) hipLaunchKernelGGL((k_rowh_permute_src<1>), dim3(grid_for(c, pairs)), dim3(256), 0, c->stream, d_src, m->src, c->XL);
