@@ -100,19 +100,18 @@ def test_engine_slab_matches_fused_path(world, n, steps, env):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-def test_engine_slab_4096_uses_the_headline_row_kernel():
-    """ny = 4096 on 2 ranks: the slab row pass is k_rowq too (slab-blocked addressing); the column side is the
-    three-kernel path on both sides (FB_FULL_PASS=0 for the single-GPU reference) -> bit-identical."""
-    import subprocess
-    import sys
-    import tempfile
+@pytest.mark.parametrize("nx,world", [(512, 2), (128, 8)])
+def test_engine_slab_4096_uses_the_headline_row_kernel(nx, world):
+    """ny = 4096 on 2 and 8 ranks (different slab widths, both column groups present): the slab row pass is k_rowq too (slab-blocked addressing); the column
+    side is the three-kernel path on both sides (nx < 4096 for the single-GPU reference) -> bit-identical."""
     import xlab_fftbarotropic_amd as X
-    nx, ny, world, steps = 512, 4096, 2, 2
+    ny, steps = 4096, 2
     rng = np.random.default_rng(5)
     v0 = (rng.standard_normal((nx, ny)) * 1e-4).astype(np.float32)
     src = (rng.standard_normal((nx, ny)) * 1e-9).astype(np.float32)
-    _, got, _ = slab_run(nx, world, steps, v0, 0.75, src=src, ny=ny)
-    ref = X.Model(nx, ny, dt=0.75)                      # nx = 512: three-kernel column path, k_rowq row pass
+    _, got, plan = slab_run(nx, world, steps, v0, 0.75, src=src, ny=ny)
+    assert plan[2:] == _slab().slab_geometry(nx, ny, world)[1:] and plan[3] > 0     # active and frozen slabs both present
+    ref = X.Model(nx, ny, dt=0.75)                      # three-kernel column path, k_rowq row pass
     ref.set_vort(v0)
     ref.set_source(src)
     ref.step(steps)
