@@ -199,16 +199,24 @@ def test_config5_16384_source_forced_on_8_ranks_full_size():
     _invariants(v0, got, with_source=True)
 
 
-def test_engine_slab_many_steps_stay_in_step():
-    """Ranks racing through 40 steps (160 stages, thousands of event hand-offs between 16 streams): any missing
+@pytest.mark.parametrize("n,world,steps,env", [(512, 4, 40, {"FB_SLAB_FIELD_GROUPS": "4", "FB_SLAB_ROW_CHUNKS": "2"}),
+                                               (4096, 4, 8, {"FB_SLAB_FIELD_GROUPS": "4", "FB_SLAB_ROW_CHUNKS": "4"}),
+                                               (4096, 8, 6, None)])
+def test_engine_slab_many_steps_stay_in_step(n, world, steps, env):
+    """Ranks racing through many stages (thousands of event hand-offs between up to 16 streams), on a small grid where the host
+    runs far ahead of the device and at the headline grid where kernels take long enough for every overlap to happen: any missing
     dependency between a rank's compute and communication streams shows up as a bit difference."""
     import xlab_fftbarotropic_amd as X
-    n, world, steps = 512, 4, 40
     v0 = X.make_field("kuo2004", n)
-    ref = X.Model(n, n)
+    dt = 3.0 if n <= 1024 else 0.75
+    os.environ["FB_FULL_PASS"] = "0"                    # the three-kernel x pass: the kernels the ranks run
+    try:
+        ref = X.Model(n, n, dt=dt)
+    finally:
+        os.environ.pop("FB_FULL_PASS", None)
     ref.set_vort(v0)
     ref.step(steps)
-    _, got, _ = slab_run(n, world, steps, v0, 3.0, env={"FB_SLAB_FIELD_GROUPS": "4", "FB_SLAB_ROW_CHUNKS": "2"})
+    _, got, _ = slab_run(n, world, steps, v0, dt, env=env)
     assert np.array_equal(got.view(np.uint32), ref.vort().cpu().numpy().view(np.uint32))
 
 
