@@ -95,6 +95,15 @@ FB_DEV void cf_xchg_lanes(cf *lds, cf *v, int w, int l, int c)
 // the scheduler interleave two radix-16 butterflies needs far more than the 128 VGPRs a
 // 1024-thread workgroup has.
 #define CF_FENCE() __builtin_amdgcn_sched_barrier(0)
+// complex multiplies as two asm statements here (fb_fft_core.h, cmul_split): measured faster in this kernel
+#ifndef CF_BFLY_SPLIT
+#define CF_BFLY_SPLIT 1
+#endif
+#ifndef CF_TW_SPLIT
+#define CF_TW_SPLIT 1
+#endif
+FB_DEV cf cf_mul(cf a, cf b) { return CF_TW_SPLIT ? cmul_split(a, b) : cmul(a, b); }
+FB_DEV cf cf_mulc(cf a, cf b) { return CF_TW_SPLIT ? cmulc_split(a, b) : cmulc(a, b); }
 
 // radix-16 butterfly with a scheduling fence after every radix-4 sub-butterfly: same arithmetic as
 // Bfly<16>, but the four independent sub-butterflies are not interleaved (a few temporaries
@@ -105,9 +114,9 @@ template <int DIR> FB_DEV void cf_bfly16(cf *v)
     fft4<DIR>(v[1], v[5], v[9], v[13]);  CF_FENCE();
     fft4<DIR>(v[2], v[6], v[10], v[14]); CF_FENCE();
     fft4<DIR>(v[3], v[7], v[11], v[15]); CF_FENCE();
-    v[5]  = mul_w16<1, DIR>(v[5]);  v[6]  = mul_w16<2, DIR>(v[6]);  v[7]  = mul_w16<3, DIR>(v[7]);
-    v[9]  = mul_w16<2, DIR>(v[9]);  v[10] = mul_w16<4, DIR>(v[10]); v[11] = mul_w16<6, DIR>(v[11]);
-    v[13] = mul_w16<3, DIR>(v[13]); v[14] = mul_w16<6, DIR>(v[14]); v[15] = mul_w16<9, DIR>(v[15]);
+    v[5]  = mul_w16<1, DIR, CF_BFLY_SPLIT != 0>(v[5]);  v[6]  = mul_w16<2, DIR, CF_BFLY_SPLIT != 0>(v[6]);  v[7]  = mul_w16<3, DIR, CF_BFLY_SPLIT != 0>(v[7]);
+    v[9]  = mul_w16<2, DIR, CF_BFLY_SPLIT != 0>(v[9]);  v[10] = mul_w16<4, DIR, CF_BFLY_SPLIT != 0>(v[10]); v[11] = mul_w16<6, DIR, CF_BFLY_SPLIT != 0>(v[11]);
+    v[13] = mul_w16<3, DIR, CF_BFLY_SPLIT != 0>(v[13]); v[14] = mul_w16<6, DIR, CF_BFLY_SPLIT != 0>(v[14]); v[15] = mul_w16<9, DIR, CF_BFLY_SPLIT != 0>(v[15]);
     CF_FENCE();
     fft4<DIR>(v[0], v[1], v[2], v[3]);     CF_FENCE();
     fft4<DIR>(v[4], v[5], v[6], v[7]);     CF_FENCE();
@@ -131,7 +140,7 @@ FB_DEV void cf_fft4096(cf *lds, const cf *tabA, const cf *tabB, cf (*v)[16], int
         for (int col = 0; col < 2; ++col) {
             cf_bfly16<-1>(v[col]);                                       // over i -> k1
 #pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1) { v[col][k1] = cmul(v[col][k1], tabB[w * k1]); if ((k1 & 3) == 3) CF_FENCE(); }
+            for (int k1 = 1; k1 < 16; ++k1) { v[col][k1] = cf_mul(v[col][k1], tabB[w * k1]); if ((k1 & 3) == 3) CF_FENCE(); }
             cf_xchg_waves(lds, v[col], w, lane);                             // now wave = k1, reg = w
             CF_FENCE();
         }
@@ -139,9 +148,9 @@ FB_DEV void cf_fft4096(cf *lds, const cf *tabA, const cf *tabB, cf (*v)[16], int
 #pragma unroll
         for (int col = 0; col < 2; ++col) {
             cf_bfly16<-1>(v[col]);                                       // over w -> k2
-            v[col][0] = cmul(v[col][0], a);
+            v[col][0] = cf_mul(v[col][0], a);
 #pragma unroll
-            for (int k2 = 1; k2 < 16; ++k2) { v[col][k2] = cmul(v[col][k2], cmul(a, tabB[l * k2])); if ((k2 & 3) == 3) CF_FENCE(); }
+            for (int k2 = 1; k2 < 16; ++k2) { v[col][k2] = cf_mul(v[col][k2], cf_mul(a, tabB[l * k2])); if ((k2 & 3) == 3) CF_FENCE(); }
             cf_xchg_lanes<false>(lds, v[col], w, l, c);                      // now l = k2, reg = l
             CF_FENCE();
         }
@@ -153,7 +162,7 @@ FB_DEV void cf_fft4096(cf *lds, const cf *tabA, const cf *tabB, cf (*v)[16], int
         for (int col = 0; col < 2; ++col) {
             cf_bfly16<+1>(v[col]);                                       // over k3 -> l (in reg)
 #pragma unroll
-            for (int lr = 1; lr < 16; ++lr) { v[col][lr] = cmulc(v[col][lr], cmul(tabA[lr * w], tabB[lr * l])); if ((lr & 3) == 3) CF_FENCE(); }
+            for (int lr = 1; lr < 16; ++lr) { v[col][lr] = cf_mulc(v[col][lr], cf_mul(tabA[lr * w], tabB[lr * l])); if ((lr & 3) == 3) CF_FENCE(); }
             if (col == 0) cf_xchg_lanes<false>(lds, v[col], w, l, c);        // now lane-l = l, reg = k2
             else cf_xchg_lanes<true>(lds, v[col], w, l, c);
             CF_FENCE();
@@ -162,7 +171,7 @@ FB_DEV void cf_fft4096(cf *lds, const cf *tabA, const cf *tabB, cf (*v)[16], int
         for (int col = 0; col < 2; ++col) {
             cf_bfly16<+1>(v[col]);                                       // over k2 -> w (in reg)
 #pragma unroll
-            for (int wr = 1; wr < 16; ++wr) { v[col][wr] = cmulc(v[col][wr], tabB[wr * w]); if ((wr & 3) == 3) CF_FENCE(); }
+            for (int wr = 1; wr < 16; ++wr) { v[col][wr] = cf_mulc(v[col][wr], tabB[wr * w]); if ((wr & 3) == 3) CF_FENCE(); }
             cf_xchg_waves(lds, v[col], w, lane);                             // now wave = w, reg = k1
             CF_FENCE();
         }

@@ -34,31 +34,49 @@ FB_DEV cf lds_rd(const cf *p) { return *p; }
 FB_DEV cf cadd(cf a, cf b) { return a + b; }
 FB_DEV cf csub(cf a, cf b) { return a - b; }
 #if defined(__HIP_DEVICE_COMPILE__)
+// Both instructions of a complex multiply sit in ONE asm statement: the compiler must assume that an asm statement
+// it cannot look into writes its result with a destination select and pads every dependent pair of statements with
+// s_nop 0 (gfx940 dst-sel forwarding rule; v_pk_*_f32 has no such hazard).  204 of k_rowq's 2492 instructions were
+// such padding.  The early-clobber result keeps a and b alive for the second instruction.
+#define FB_CMUL_ASM_FUSED(MODS, BC) \
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] " MODS \
+        : "=&v"(r) : "v"(a), BC(b))
+#define FB_CMUL_ASM_SPLIT(MODS, BC) \
+    { cf t_; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t_) : "v"(a), BC(b)); \
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] " MODS : "=v"(r) : "v"(a), BC(b), "v"(t_)); }
+#ifndef FB_SPLIT_CMUL_ASM
+#define FB_CMUL_ASM(MODS, BC) FB_CMUL_ASM_FUSED(MODS, BC)
+#else
+#define FB_CMUL_ASM(MODS, BC) FB_CMUL_ASM_SPLIT(MODS, BC)
+#endif
 // a*b = (a.x b.x - a.y b.y, a.x b.y + a.y b.x):  t = (a.y b.y, a.y b.x);  r = (a.x b.x - t.x, a.x b.y + t.y)
 FB_DEV cf cmul(cf a, cf b)
 {
-    cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    cf r;
+    FB_CMUL_ASM("neg_lo:[0,0,1]", "v");
     return r;
 }
 // a*conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
 FB_DEV cf cmulc(cf a, cf b)
 {
-    cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    cf r;
+    FB_CMUL_ASM("neg_hi:[0,1,0]", "v");
     return r;
 }
 // same with the second factor in an SGPR pair (compile-time constants)
 FB_DEV cf cmul_k(cf a, cf k)
 {
-    cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(k));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "s"(k), "v"(t));
+    const cf b = k;
+    cf r;
+    FB_CMUL_ASM("neg_lo:[0,0,1]", "s");
     return r;
 }
+// the two-statement forms (k_col_full schedules better with them: 0.150 against 0.154 ms at 4096^2, 0.66 against 0.69 ms at 8192^2)
+FB_DEV cf cmul_split(cf a, cf b) { cf r; FB_CMUL_ASM_SPLIT("neg_lo:[0,0,1]", "v"); return r; }
+FB_DEV cf cmulc_split(cf a, cf b) { cf r; FB_CMUL_ASM_SPLIT("neg_hi:[0,1,0]", "v"); return r; }
+FB_DEV cf cmul_k_split(cf a, cf k) { const cf b = k; cf r; FB_CMUL_ASM_SPLIT("neg_lo:[0,0,1]", "s"); return r; }
 // a + i b = (a.x - b.y, a.y + b.x) ;  a - i b = (a.x + b.y, a.y - b.x)
+#ifndef FB_SCALAR_ROT
 FB_DEV cf cadd_ib(cf a, cf b)
 {
     cf r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
@@ -68,9 +86,16 @@ FB_DEV cf csub_ib(cf a, cf b)
     cf r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
 #else
+FB_DEV cf cadd_ib(cf a, cf b) { return cf_make(a.x - b.y, a.y + b.x); }
+FB_DEV cf csub_ib(cf a, cf b) { return cf_make(a.x + b.y, a.y - b.x); }
+#endif
+#else
 FB_DEV cf cmul(cf a, cf b) { return cf_make(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 FB_DEV cf cmulc(cf a, cf b) { return cf_make(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 FB_DEV cf cmul_k(cf a, cf k) { return cmul(a, k); }
+FB_DEV cf cmul_split(cf a, cf b) { return cmul(a, b); }
+FB_DEV cf cmulc_split(cf a, cf b) { return cmulc(a, b); }
+FB_DEV cf cmul_k_split(cf a, cf k) { return cmul(a, k); }
 FB_DEV cf cadd_ib(cf a, cf b) { return cf_make(a.x - b.y, a.y + b.x); }
 FB_DEV cf csub_ib(cf a, cf b) { return cf_make(a.x + b.y, a.y - b.x); }
 #endif
@@ -111,7 +136,7 @@ template <bool NT> FB_DEV void st2(cf *p, cf v) { if (NT) __builtin_nontemporal_
 #define FB_S16_1 0.38268343236508977173f   /* sin(pi/8) */
 
 // multiply by W_16^M (forward) or its conjugate (backward), M in 0..15 compile-time
-template <int M, int DIR> FB_DEV cf mul_w16(cf a)
+template <int M, int DIR, bool SPLIT = false> FB_DEV cf mul_w16(cf a)
 {
     constexpr int m = M & 15;
     if constexpr (m == 0) return a;
@@ -127,7 +152,7 @@ template <int M, int DIR> FB_DEV cf mul_w16(cf a)
                             (m == 3 || m == 5) ? FB_C16_1 : (m == 9 || m == 15) ? -FB_S16_1 :
                             (m == 10 || m == 14) ? -FB_SQRT1_2 : /* 11, 13 */ -FB_C16_1;
         constexpr float si = DIR < 0 ? -s : s;       // imaginary part of the twiddle
-        return cmul_k(a, cf_make(c, si));
+        return SPLIT ? cmul_k_split(a, cf_make(c, si)) : cmul_k(a, cf_make(c, si));
     }
 }
 

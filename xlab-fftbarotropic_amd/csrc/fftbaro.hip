@@ -713,47 +713,77 @@ static int autotune_pitch(fb_ctx *c)
     if (c->world != 1 || getenv("FB_PITCH_EXTRA") || getenv("FB_NO_PITCH_TUNE")) return FB_OK;
     if ((size_t)c->nx * c->P * sizeof(cf) < ((size_t)32 << 20)) return FB_OK;      // cache-resident grids: nothing to gain
     const int nsub = full_pass_nsub(c);
-    const int P0 = c->P, NC = nsub ? 5 : 4;
+    const int P0 = c->P, NC = nsub ? 7 : 4;                                        // create_impl leaves room for P0 + 96
+    if (nsub && !getenv("FB_PITCH_TUNE")) {
+        // single-pass x transform: a fixed rule.  tools/pitch_scan.sh on three boxes: round16(ny/2 + 1) is the slowest pitch at
+        // 4096^2 (k_col_full 0.1525-0.1556 ms against 0.148-0.152 for every other candidate) and, with + 16, at 8192^2 (0.75 / 0.79 ms
+        // against 0.65-0.69 for + 32, + 64, + 96 and 0.69-0.72 for + 48, + 80).  The probe below (FB_PITCH_TUNE=1) sees the same
+        // ordering on average but not reliably in one process: its buffers land on other physical pages than the model's, which
+        // moves a candidate by up to 5 % at 8192^2, more than what separates the good pitches.
+        c->P = c->KA = c->katot = c->grp[0].ncols = P0 + 32;
+        finish_groups(c);
+        return FB_OK;
+    }
     const size_t maxe = (size_t)c->nx * (P0 + 16 * (NC - 1));
     // the probe is the pitch-sensitive kernel of the path the model will take: the backward strided sub-pass of one field, or
-    // k_col_full's PRIME launch (64-byte row segments of four derivative fields, rows P*8 bytes apart)
+    // a stage-1 launch of k_col_full (tendency in, three state arrays, 64-byte row segments of four derivative fields out, rows
+    // P*8 bytes apart) on zeroed buffers.  tools/pitch_scan.sh: the step time follows this probe; PRIME launches with two
+    // repetitions per candidate (the first version) did not resolve the 2-4 % between pitches and often kept the worst one.
+    const int nbuf = nsub ? 9 : 1;           // k_col_full: Tin, 4 x W4, Z0, Zc, Acc, Zout
     cf *buf = nullptr;
-    if (hipMalloc((void **)&buf, maxe * (nsub ? 5 : 1) * sizeof(cf)) != hipSuccess) { hipGetLastError(); return FB_OK; }
-    hipMemsetAsync(buf, 0, maxe * (nsub ? 5 : 1) * sizeof(cf), c->stream);
+    if (hipMalloc((void **)&buf, maxe * nbuf * sizeof(cf)) != hipSuccess) { hipGetLastError(); return FB_OK; }
+    hipMemsetAsync(buf, 0, maxe * nbuf * sizeof(cf), c->stream);
     if (nsub) {
-        const void *fn = nsub == 1 ? (const void *)k_col_full<4, 1> : (const void *)k_col_full<4, 2>;
+        const void *fn = nsub == 1 ? (const void *)k_col_full<1, 1> : (const void *)k_col_full<1, 2>;
         if (set_max_lds(c, fn, CF_LDS_BYTES)) { hipFree(buf); return FB_OK; }
     }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    float best = 1e30f; int bestP = P0;
-    for (int k = 0; k < NC; ++k) {
-        ColGroup G = c->grp[0]; G.ncols = P0 + 16 * k;
-        float tmin = 1e30f;
-        for (int rep = 0; rep < 3; ++rep) {
-            int rc = FB_OK;
+    auto probe = [&](int P) -> int {
+        ColGroup G = c->grp[0]; G.ncols = P;
+        if (!nsub) return launch_col_strided<+1>(c, G, buf, 1, 0);
+        FullArgs a; memset(&a, 0, sizeof(a));
+        a.Tin = buf; a.W4 = buf + maxe; a.Zbase = buf + 5 * maxe; a.Zcur = buf + 6 * maxe; a.Acc = buf + 7 * maxe; a.Zout = buf + 8 * maxe;
+        a.fstride = (long)c->nx * P; a.P = P; a.ntiles = (c->ny / 2) / 8;
+        a.ntiles_run = a.ntiles; a.nsub = nsub; a.stage = 1; a.nu = 0.f; a.dt = 0.f; a.coef = make_coef(c); a.tw256 = c->d_tw_256;
+        a.tw4096 = nsub == 1 ? c->d_tw_big : c->d_tw_4096; a.sub_rows = 4096;
+        const dim3 g(nsub * a.ntiles), b(CF_THREADS);
+        if (nsub == 1) hipLaunchKernelGGL((k_col_full<1, 1>), g, b, CF_LDS_BYTES, c->stream, a);
+        else hipLaunchKernelGGL((k_col_full<1, 2>), g, b, CF_LDS_BYTES, c->stream, a);
+        return hipGetLastError() == hipSuccess ? FB_OK : FB_EHIP;
+    };
+    const bool verbose = getenv("FB_TUNE_VERBOSE") != nullptr;
+    // the device needs ~25 ms of this load to reach full speed: run the probe that long before timing it
+    hipEventRecord(e0, c->stream);
+    for (int it = 0; it < 400; ++it) {
+        if (probe(P0) != FB_OK) break;
+        if ((it & 7) == 7) {
+            hipEventRecord(e1, c->stream); hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms > 30.f) break;
+        }
+    }
+    float tbest[8]; for (int k = 0; k < NC; ++k) tbest[k] = 1e30f;
+    for (int rep = 0; rep < 6; ++rep)            // candidates interleaved, so that a drift of the clock hits all of them alike
+        for (int k = 0; k < NC; ++k) {
             hipEventRecord(e0, c->stream);
-            if (nsub) {
-                FullArgs a; memset(&a, 0, sizeof(a));
-                a.Zbase = buf; a.W4 = buf + maxe; a.fstride = (long)c->nx * G.ncols; a.P = G.ncols; a.ntiles = (c->ny / 2) / 8;
-                a.ntiles_run = a.ntiles + 1; a.nsub = nsub; a.stage = 4; a.coef = make_coef(c); a.tw256 = c->d_tw_256;
-                a.tw4096 = nsub == 1 ? c->d_tw_big : c->d_tw_4096; a.sub_rows = 4096;
-                const dim3 g(nsub * (a.ntiles + 1)), b(CF_THREADS);
-                if (nsub == 1) hipLaunchKernelGGL((k_col_full<4, 1>), g, b, CF_LDS_BYTES, c->stream, a);
-                else hipLaunchKernelGGL((k_col_full<4, 2>), g, b, CF_LDS_BYTES, c->stream, a);
-                if (hipGetLastError() != hipSuccess) rc = FB_EHIP;
-            } else rc = launch_col_strided<+1>(c, G, buf, 1, 0);
+            const int rc = probe(P0 + 16 * k);
             hipEventRecord(e1, c->stream);
             hipEventSynchronize(e1);
             float ms = 0.f;
-            if (rc == FB_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0 && ms < tmin) tmin = ms;
+            if (rc == FB_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < tbest[k]) tbest[k] = ms;
         }
-        if (tmin < best * 0.97f) { best = tmin; bestP = G.ncols; }     // a larger pitch must win by 3 % to be taken
+    float best = 1e30f; int bestP = P0;
+    for (int k = 0; k < NC; ++k) {
+        if (verbose) fprintf(stderr, "fftbaro: pitch probe P=%d %.4f ms\n", P0 + 16 * k, tbest[k]);
+        if (tbest[k] < best * 0.99f) { best = tbest[k]; bestP = P0 + 16 * k; }     // a larger pitch must win by 1 % to be taken
     }
+    if (verbose) fprintf(stderr, "fftbaro: pitch %d -> %d\n", P0, bestP);
     c->P = c->KA = c->katot = c->grp[0].ncols = bestP;
     finish_groups(c);
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(buf);
+    hipGetLastError();
     return FB_OK;
 }
 
