@@ -75,6 +75,9 @@ FB_DEV cf cmul_k(cf a, cf k)
 FB_DEV cf cmul_split(cf a, cf b) { cf r; FB_CMUL_ASM_SPLIT("neg_lo:[0,0,1]", "v"); return r; }
 FB_DEV cf cmulc_split(cf a, cf b) { cf r; FB_CMUL_ASM_SPLIT("neg_hi:[0,1,0]", "v"); return r; }
 FB_DEV cf cmul_k_split(cf a, cf k) { const cf b = k; cf r; FB_CMUL_ASM_SPLIT("neg_lo:[0,0,1]", "s"); return r; }
+// a + conj(b) and a - conj(b) in one instruction each (the component-wise form costs two v_pk_add and three v_mov)
+FB_DEV cf cadd_conj(cf a, cf b) { cf r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+FB_DEV cf csub_conj(cf a, cf b) { cf r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // a + i b = (a.x - b.y, a.y + b.x) ;  a - i b = (a.x + b.y, a.y - b.x)
 #ifndef FB_SCALAR_ROT
 FB_DEV cf cadd_ib(cf a, cf b)
@@ -96,6 +99,8 @@ FB_DEV cf cmul_k(cf a, cf k) { return cmul(a, k); }
 FB_DEV cf cmul_split(cf a, cf b) { return cmul(a, b); }
 FB_DEV cf cmulc_split(cf a, cf b) { return cmulc(a, b); }
 FB_DEV cf cmul_k_split(cf a, cf k) { return cmul(a, k); }
+FB_DEV cf cadd_conj(cf a, cf b) { return cf_make(a.x + b.x, a.y - b.y); }
+FB_DEV cf csub_conj(cf a, cf b) { return cf_make(a.x - b.x, a.y + b.y); }
 FB_DEV cf cadd_ib(cf a, cf b) { return cf_make(a.x - b.y, a.y + b.x); }
 FB_DEV cf csub_ib(cf a, cf b) { return cf_make(a.x + b.y, a.y - b.x); }
 #endif

@@ -164,8 +164,8 @@ template <int V> FB_DEV void rh_ext(cf (*v)[8], int t, const cf *stg, const cf *
             const int k = V * (t + 512 * e) + s;
             cf a = lds_rd(&stg[k]), b = lds_rd(&stg[M - k]);
             if (e == 0 && s == 0 && t == 0) { a.y = 0.f; b.y = 0.f; }                  // k = 0: X[0] and X[M] count as real
-            const cf ev = cf_make(a.x + b.x, a.y - b.y);                               // X[k] + conj X[M-k]
-            cf d = cmul(cf_make(a.x - b.x, a.y + b.y), wx[s]);                         // (X[k] - conj X[M-k]) e^{2 pi i (V t + s)/N} ...
+            const cf ev = cadd_conj(a, b);                               // X[k] + conj X[M-k]
+            cf d = cmul(csub_conj(a, b), wx[s]);                         // (X[k] - conj X[M-k]) e^{2 pi i (V t + s)/N} ...
             switch (e) {                                                               // ... e^{2 pi i e/16}
             case 1: d = mul_w16<1, +1>(d); break; case 2: d = mul_w16<2, +1>(d); break; case 3: d = mul_w16<3, +1>(d); break;
             case 4: d = mul_w16<4, +1>(d); break; case 5: d = mul_w16<5, +1>(d); break; case 6: d = mul_w16<6, +1>(d); break;
@@ -337,8 +337,8 @@ FB_DEV void rh2_ext(cf *v, int t, const cf *stg0, const cf *stg1, cf wh, cf wx)
         cf a = cadd(lds_rd(&stg0[k]), cmul(lds_rd(&stg1[k]), wh));                    // X_h[k]
         cf b = cadd(lds_rd(&stg0[M - k]), cmul(lds_rd(&stg1[M - k]), wh));            // X_h[M-k]
         if (e == 0 && t == 0) { a.y = 0.f; b.y = 0.f; }                               // k = 0: X[0] and X[M] count as real
-        const cf ev = cf_make(a.x + b.x, a.y - b.y);
-        cf d = cmul(cf_make(a.x - b.x, a.y + b.y), wx);
+        const cf ev = cadd_conj(a, b);
+        cf d = cmul(csub_conj(a, b), wx);
         switch (e) {
         case 1: d = mul_w16<1, +1>(d); break; case 2: d = mul_w16<2, +1>(d); break; case 3: d = mul_w16<3, +1>(d); break;
         case 4: d = mul_w16<4, +1>(d); break; case 5: d = mul_w16<5, +1>(d); break; case 6: d = mul_w16<6, +1>(d); break;

@@ -117,8 +117,8 @@ FB_DEV void rq_ext(cf *v, int t, const cf *stg, cf wx /* exp(+2 pi i t/N) */)
         const int k = t + 256 * e;
         cf a = lds_rd(&stg[k]), b = lds_rd(&stg[M - k]);
         if (e == 0 && t == 0) { a.y = 0.f; b.y = 0.f; }                               // k = 0: X[0] and X[M] count as real (SURVEY note N2)
-        const cf ev = cf_make(a.x + b.x, a.y - b.y);
-        cf d = cmul(cf_make(a.x - b.x, a.y + b.y), wx);
+        const cf ev = cadd_conj(a, b);
+        cf d = cmul(csub_conj(a, b), wx);
         switch (e) {                                                                   // e^{2 pi i 256 e/4096} = e^{2 pi i e/16}
         case 1: d = mul_w16<1, +1>(d); break; case 2: d = mul_w16<2, +1>(d); break; case 3: d = mul_w16<3, +1>(d); break;
         case 4: d = mul_w16<4, +1>(d); break; case 5: d = mul_w16<5, +1>(d); break; case 6: d = mul_w16<6, +1>(d); break;
