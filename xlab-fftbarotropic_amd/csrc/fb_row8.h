@@ -34,12 +34,12 @@ struct Row8 {
 };
 
 // swap the register index with the wave index (workgroup-wide)
-FB_DEV void r8_xch_group(cf *v, cf *xbuf, int w, int l)
+template <bool LEAD = true> FB_DEV void r8_xch_group(cf *v, cf *xbuf, int w, int l)
 {
 #ifdef FB_R8_NOXG   /* timing experiment only */
     return;
 #endif
-    lds_barrier();                                    // every wave is done with its slice
+    if (LEAD) lds_barrier();                          // every wave is done with its slice (LEAD = false: the caller has had a workgroup barrier since the slices were last read -- the backward transforms, which start right behind the staging barriers of their phase)
 #pragma unroll
     for (int p = 0; p < 8; ++p) lds_wr(&xbuf[p * Row8::SLICE + w * 64 + l], v[p]);
     lds_barrier();
@@ -74,7 +74,7 @@ FB_DEV void r8_bwd(cf *v, cf *xbuf, const Row8Tw &tw, int w, int l)
     Bfly<8, +1>::run(v);
 #pragma unroll
     for (int p = 1; p < 8; ++p) v[p] = cmulc(v[p], tw.w0[p - 1]);
-    r8_xch_group(v, xbuf, w, l);
+    r8_xch_group<false>(v, xbuf, w, l);
     Bfly<8, +1>::run(v);
 #pragma unroll
     for (int p = 1; p < 8; ++p) v[p] = cmulc(v[p], tw.w1[p - 1]);

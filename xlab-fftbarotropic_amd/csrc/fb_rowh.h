@@ -33,14 +33,16 @@ template <int V> struct RowH {
 };
 
 // ---- the M-point transforms on v[V][8]: sub-sequence s holds Z[V q + s], q = t + 512 e (natural order) ----------------
-template <int V> FB_DEV void rh_xch_group(cf (*v)[8], cf *xbuf, int w, int l)
+struct RhNothing { FB_DEV void operator()() const {} };
+template <int V, bool LEAD = true, class F = RhNothing> FB_DEV void rh_xch_group(cf (*v)[8], cf *xbuf, int w, int l, F &&behind_barrier = F())
 {
-    lds_barrier();                                    // every wave is done with its slices
+    if (LEAD) lds_barrier();                          // every wave is done with its slices (not needed by the backward transforms: r8_xch_group)
 #pragma unroll
     for (int s = 0; s < V; ++s)
 #pragma unroll
         for (int p = 0; p < 8; ++p) lds_wr(&xbuf[s * RowH<V>::XSUB + p * Row8::SLICE + w * 64 + l], v[s][p]);
     lds_barrier();
+    behind_barrier();                                 // (backward: every wave has also left the staged row behind -- send for the next one)
 #pragma unroll
     for (int s = 0; s < V; ++s)
 #pragma unroll
@@ -49,7 +51,7 @@ template <int V> FB_DEV void rh_xch_group(cf (*v)[8], cf *xbuf, int w, int l)
 
 // backward: natural order in, digit-reversed out: sub-transform output F_s[j'] with j' = w + 8 l_hi + 64 l_lo + 512 e; then
 // (V = 2) z[j'] = F_0 + W^{-j'} F_1 and z[j' + 4096] = F_0 - W^{-j'} F_1 with W = exp(-2 pi i/M), left in v[0][e], v[1][e]
-template <int V> FB_DEV void rh_bwd(cf (*v)[8], cf *xbuf, const Row8Tw &tw, cf wq, int w, int l)
+template <int V, class F> FB_DEV void rh_bwd(cf (*v)[8], cf *xbuf, const Row8Tw &tw, cf wq, int w, int l, F &&behind_barrier)
 {
     const int l_hi = l >> 3, l_lo = l & 7;
 #pragma unroll
@@ -58,7 +60,7 @@ template <int V> FB_DEV void rh_bwd(cf (*v)[8], cf *xbuf, const Row8Tw &tw, cf w
 #pragma unroll
         for (int p = 1; p < 8; ++p) v[s][p] = cmulc(v[s][p], tw.w0[p - 1]);
     }
-    rh_xch_group<V>(v, xbuf, w, l);
+    rh_xch_group<V, false>(v, xbuf, w, l, behind_barrier);
 #pragma unroll
     for (int s = 0; s < V; ++s) {
         cf *slice = xbuf + s * RowH<V>::XSUB + w * Row8::SLICE;
@@ -237,9 +239,15 @@ __global__ void __launch_bounds__(512, RowH<V>::MIN_WAVES) k_rowh(RowArgs a, con
             if (wait) RH_WAIT_ROW();                                  // (the first phase's row was waited for before the previous stores)
             lds_barrier();
             rh_ext<V>(v, tp, stg, wx);
+#ifndef RH_LATE_DMA   /* -DRH_LATE_DMA: the next row is sent for behind the exchange barrier instead (one barrier fewer per phase; measured: no gain at ny = 4096 and 16384, 2 % slower in k_rowh2) */
             lds_barrier();
             if (next_row >= 0) rh_dma_issue<V, SLAB>(stg, tp, a.M, next_field, next_row);
-            rh_bwd<V>(v, xbuf, tw, wq, tp >> 6, tp & 63);
+            rh_bwd<V>(v, xbuf, tw, wq, tp >> 6, tp & 63, RhNothing());
+#else
+            // the next row is sent for behind the barrier of the transform's own workgroup-wide exchange: by then every wave has
+            // read what it needs of the staged row
+            rh_bwd<V>(v, xbuf, tw, wq, tp >> 6, tp & 63, [&] { if (next_row >= 0) rh_dma_issue<V, SLAB>(stg, tp, a.M, next_field, next_row); });
+#endif
         };
         c2r_phase(false, 2, x);                                       // d vort/dx                         main.cpp:154
 #pragma unroll
@@ -395,9 +403,13 @@ __global__ void __launch_bounds__(1024) k_rowh2(RowArgs a, const cf *__restrict_
             if (wait) RH_WAIT_ROW();
             lds_barrier();
             rh2_ext(v, tp, stg0, stg1, wh, wx);
+#ifndef RH_LATE_DMA
             lds_barrier();
             if (next_x2 >= 0) rh_dma_issue<1, false>(stgh, tp, a.M, next_field, (int)(h * sub) + next_x2);
-            rh_bwd<1>(v1, xbuf, tw, wq, tp >> 6, tp & 63);
+            rh_bwd<1>(v1, xbuf, tw, wq, tp >> 6, tp & 63, RhNothing());
+#else
+            rh_bwd<1>(v1, xbuf, tw, wq, tp >> 6, tp & 63, [&] { if (next_x2 >= 0) rh_dma_issue<1, false>(stgh, tp, a.M, next_field, (int)(h * sub) + next_x2); });
+#endif
         };
         c2r_phase(false, 2, x2);                                      // d vort/dx                         main.cpp:154
 #pragma unroll

@@ -30,12 +30,14 @@ struct RowQTw { cf w0[7], w1[3]; const cf *w2; };              // W_2048^{p t}, 
 // G exchange.  Element p of the stage-0 output of wave w goes to wave p & 3 as register (q = w, h = p >> 2); it travels through
 // the RECEIVING wave's slice, [p & 3][(p >> 2) * 4 + w][lane], so that after the barrier every wave reads its own slice only and
 // may go on to the wave-private exchanges without another barrier.
-FB_DEV void rq_xch_group_bwd(cf *v, cf *xbuf, int w, int l)
+template <class F> FB_DEV void rq_xch_group_bwd(cf *v, cf *xbuf, int w, int l, F &&behind_barrier)
 {
-    lds_barrier();                                    // every wave is done with its slice
+    // no barrier in front: the slices were last read by the previous transform's wave-private exchanges, and the caller has passed the
+    // staging barriers of this phase since
 #pragma unroll
     for (int p = 0; p < 8; ++p) lds_wr(&xbuf[(p & 3) * RowQ::SLICE + ((p >> 2) * 4 + w) * 64 + l], v[p]);
     lds_barrier();
+    behind_barrier();                                 // every wave has also left the staged row behind: the next one may be sent for
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = lds_rd(&xbuf[w * RowQ::SLICE + j * 64 + l]);         // j = 4 h + q
 }
@@ -50,14 +52,14 @@ FB_DEV void rq_xch_group_fwd(cf *v, cf *xbuf, int w, int l)
     lds_barrier();                                    // the slices are free again
 }
 
-FB_DEV void rq_bwd(cf *v, cf *xbuf, const RowQTw &tw, int w, int l)
+template <class F> FB_DEV void rq_bwd(cf *v, cf *xbuf, const RowQTw &tw, int w, int l, F &&behind_barrier)
 {
     const int l_hi = l >> 3, l_lo = l & 7;
     cf *slice = xbuf + w * RowQ::SLICE;
     Bfly<8, +1>::run(v);
 #pragma unroll
     for (int p = 1; p < 8; ++p) v[p] = cmulc(v[p], tw.w0[p - 1]);
-    rq_xch_group_bwd(v, xbuf, w, l);
+    rq_xch_group_bwd(v, xbuf, w, l, behind_barrier);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         fft4<+1>(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
@@ -188,9 +190,15 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const cf *__restrict
             if (wait) RH_WAIT_ROW();
             lds_barrier();
             rq_ext(v, tp, stg, wx);
+#ifndef RQ_LATE_DMA   /* -DRQ_LATE_DMA: the next row is sent for behind the exchange barrier instead (one barrier fewer per phase; measured: no gain at ny = 4096 and 16384, 2 % slower in k_rowh2) */
             lds_barrier();
             if (next_row >= 0) rq_dma_issue<SLAB>(stg, tp, a.M, next_field, next_row);
-            rq_bwd(v, xbuf, tw, tp >> 6, tp & 63);
+            rq_bwd(v, xbuf, tw, tp >> 6, tp & 63, [] {});
+#else
+            // the next row is sent for behind the barrier of the transform's own four-wave exchange: by then every wave has read
+            // what it needs of the staged row
+            rq_bwd(v, xbuf, tw, tp >> 6, tp & 63, [&] { if (next_row >= 0) rq_dma_issue<SLAB>(stg, tp, a.M, next_field, next_row); });
+#endif
         };
         c2r_phase(false, 2, x);                                       // d vort/dx                         main.cpp:154
 #pragma unroll
