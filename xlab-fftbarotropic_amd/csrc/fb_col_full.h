@@ -240,7 +240,10 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
         for (int i = 0; i < 4; ++i) g4[i] = a.coef.gx[nsub * (tid + i * CF_THREADS) + k1];      // gradx_coe at kx = nsub k2 + k1
         if (tid < 256) { tabB[tid] = a.tw256[tid]; tabA[tid] = a.tw4096[tid]; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gxt[tid + i * CF_THREADS] = g4[i];
+        for (int i = 0; i < 4; ++i) {                   // kx2 = w + 16 l + 256 k3 sits at l + 16 w + 256 k3: the lanes of a wave (l) read neighbours
+            const int ik = tid + i * CF_THREADS;
+            gxt[((ik >> 4) & 15) + 16 * (ik & 15) + (ik & ~255)] = g4[i];
+        }
         if (!PRIME) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { v[0][i] = cf_make(tin[i].x, tin[i].y); v[1][i] = cf_make(tin[i].z, tin[i].w); }
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
         for (int j = 0; j < KB; ++j) {
             const int k3 = b * KB + j;
             const int ik2 = w + 256 * k3 + 16 * l, ikx = nsub * ik2 + k1;
-            const float gx = gxt[ik2];
+            const float gx = gxt[l + 16 * w + 256 * k3];
             const double kx2 = (double)gx * (double)gx;                      // fftwfop.cpp:42,45
             const float lapa = (float)(-(kx2 + ky2a)), lapb = (float)(-(kx2 + ky2b));
             const float mska = coef_mask(a.coef, ikx, ky0), mskb = coef_mask(a.coef, ikx, ky0 + 1);
@@ -334,11 +337,11 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
             }
         }
         const bool psi = f >= 2, use_gx = (f == 0 || f == 3);
-        const int lkx = launder(16 * l);                          // per-iteration copy: keeps the table addresses inside the loop
+        const int lkx = launder(l);                               // per-iteration copy: keeps the table addresses inside the loop
 #pragma unroll
         for (int k3 = 0; k3 < 16; ++k3) {
             cf za = v[0][k3], zb = v[1][k3];
-            const float gx = gxt[w + 256 * k3 + lkx];
+            const float gx = gxt[16 * w + 256 * k3 + lkx];
             if (psi) {                                // psi_c = invertLaplacian(vort_c)   main.cpp:179
                 const double kx2 = (double)gx * (double)gx;
                 const float lia = (nsub * (w + 256 * k3 + 16 * l) + k1 == 0 && ky0 == 0) ? 1.0f : (float)(-(kx2 + ky2a));
