@@ -655,3 +655,25 @@ def test_single_pass_8192_matches_three_kernel_path_and_oracle(O, R):
     assert R.rel_l2(outs["1"]["vort"], mo.vort()[::4, ::4]) < 1e-5
     assert R.rel_l2(outs["1"]["spec"].view(np.float32), np.ascontiguousarray(mo.spectrum()[:, ::5]).view(np.float32)) < 1e-5
     assert R.rel_l2(outs["1"]["u"], mo.diag()[1][::8, ::8]) < 1e-5
+
+
+def test_stage1_state_recompute_is_bitwise_neutral(tmp_path):
+    """k_col_full's stage 1 does not read the stage state back but forms it again as fma(rk1, dt/2, vort_c0) from the accumulator
+    that stage 0 stored (fb_col_full.h, REMAKE_ZC).  A library built with -DCF_REMAKE_ZC=0 (the state is read back) must give the
+    same bits after 2 steps of a noisy 4096^2 state (tools/cmp_variants.py runs each build in its own process)."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(HERE)
+    alt = os.path.join(root, "xlab-fftbarotropic_amd", "lib", "alt_nozc_test.so")
+    try:
+        subprocess.check_call([os.path.join(root, "tools", "build_variant.sh"), "nozc_test", "-DCF_REMAKE_ZC=0"], timeout=900)
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "cmp_variants.py"), alt, "4096", "2"], stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.count("bitwise equal") == 2, out.stdout
+    finally:
+        if os.path.exists(alt):
+            os.remove(alt)

@@ -256,71 +256,74 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
     const char *Z0 = reinterpret_cast<const char *>(a.Zbase) + ubase_s;
     char *ZC = reinterpret_cast<char *>(a.Zcur) + ubase_s, *AC = reinterpret_cast<char *>(a.Acc) + ubase_s,
          *ZO = reinterpret_cast<char *>(a.Zout) + ubase_s;
-    const double ky2a = a.coef.ky2[ky0], ky2b = a.coef.ky2[ky0 + 1];
     const float gya = a.coef.gy[ky0], gyb = a.coef.gy[ky0 + 1];
+    // ky^2 is formed where it is used, (double)gy * (double)gy == the ky2 table entry (fftbaro.hip: h_ky2), from an opaque copy of gy:
+    // held as doubles the two of them cost four registers for the whole tile (this kernel has none to spare)
+    auto ky2_of = [](float g) { asm volatile("" : "+v"(g)); return (double)g * (double)g; };
     constexpr bool PRIME_ = STAGE == 4;
     const bool pada = PRIME_ && ky0 >= a.coef.hy, padb = PRIME_ && ky0 + 1 >= a.coef.hy;      // PRIME's last tile: columns beyond ny/2 are zero padding
     constexpr int stage = STAGE;
     const float nu = a.nu, dt = a.dt, hdt = (stage == 2) ? a.dt : a.dt / 2.0f;
-    // The state arrays move in batches of two k3: the loads of batch b+1 are issued before the stores of batch b,
+    // The state arrays move one k3 at a time, CF_DEPTH k3 ahead: the loads of k3 + CF_DEPTH are issued before the stores of k3,
     // so no load is ever queued right behind a store (whose acknowledgement it would have to wait for).
-    constexpr int KB = 1, NBATCH = 16 / KB;
-    float4 q0[KB], q1[KB], q2[KB], accp[KB];
-    auto load_batch = [&](int b) {
-#pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const int k3 = b * KB + j;
-            q0[j] = cf_ld4(Z0 + k3 * sstep, voff_s);
-            if (stage != 0) { q1[j] = cf_ld4(ZC + k3 * sstep, voff_s); q2[j] = ld4<CF_NT_ACC != 0>(AC + k3 * sstep + voff_s); }
-        }
+    // Two k3 ahead where the registers allow it: stage 0 reads one array (0.140 -> 0.137 ms); with three arrays a depth of 2 spills
+    // 100-250 B per lane and loses 3-6 %.
+#ifndef CF_DEPTH
+#define CF_DEPTH (STAGE == 0 ? 2 : 1)
+#endif
+    constexpr int DEPTH = CF_DEPTH;
+    // Stage 1 does not read its stage state back: what stage 0 stored is fma(rk1, dt/2, vort_c0) with rk1 == the accumulator it also
+    // stored, so the same instruction on the same bits gives it again (one array read less, 0.94 C of this launch's 12.6 C).
+#ifndef CF_REMAKE_ZC
+#define CF_REMAKE_ZC 1
+#endif
+    constexpr bool REMAKE_ZC = CF_REMAKE_ZC && STAGE == 1;
+    float4 q0[DEPTH], q1[DEPTH], q2[DEPTH];
+    auto load_k3 = [&](int k3) {
+        const int sl = k3 % DEPTH;
+        q0[sl] = cf_ld4(Z0 + k3 * sstep, voff_s);
+        if (stage != 0) q2[sl] = ld4<CF_NT_ACC != 0>(AC + k3 * sstep + voff_s);
+        if (stage != 0 && !REMAKE_ZC) q1[sl] = cf_ld4(ZC + k3 * sstep, voff_s);
     };
-    auto store_batch = [&](int b) {
+    if (!PRIME) {
 #pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const int k3 = b * KB + j;
-            const float4 zn = make_float4(v[0][k3].x, v[0][k3].y, v[1][k3].x, v[1][k3].y);
-            if (stage < 3) { st4<CF_NT_ACC != 0>(AC + k3 * sstep + voff_s, accp[j]); cf_st4(ZC + k3 * sstep, voff_s, zn); }
-            else cf_st4(ZO + k3 * sstep, voff_s, zn);
+        for (int k3 = 0; k3 < DEPTH; ++k3) load_k3(k3);
+    }
+#pragma unroll
+    for (int k3 = 0; k3 < (PRIME ? 0 : 16); ++k3) {
+        const int sl = k3 % DEPTH;
+        const int ik2 = w + 256 * k3 + 16 * l, ikx = nsub * ik2 + k1;
+        const float gx = gxt[l + 16 * w + 256 * k3];
+        const double kx2 = (double)gx * (double)gx;                      // fftwfop.cpp:42,45
+        const float lapa = (float)(-(kx2 + ky2_of(gya))), lapb = (float)(-(kx2 + ky2_of(gyb)));
+        const float mska = coef_mask(a.coef, ikx, ky0), mskb = coef_mask(a.coef, ikx, ky0 + 1);
+        const float4 z0 = q0[sl];
+        float4 zc = z0;
+        if (REMAKE_ZC) {
+            const float4 ac = q2[sl];
+            zc = make_float4(__builtin_fmaf(ac.x, hdt, z0.x), __builtin_fmaf(ac.y, hdt, z0.y), __builtin_fmaf(ac.z, hdt, z0.z), __builtin_fmaf(ac.w, hdt, z0.w));
+        } else if (stage != 0) zc = q1[sl];
+        float4 k;
+        k.x = (v[0][k3].x + (zc.x * lapa) * nu) * mska; k.y = (v[0][k3].y + (zc.y * lapa) * nu) * mska;
+        k.z = (v[1][k3].x + (zc.z * lapb) * nu) * mskb; k.w = (v[1][k3].y + (zc.w * lapb) * nu) * mskb;
+        float4 acc, zn;
+        if (stage == 0) {
+            acc = k;                   // (explicit fma: stage 1 recomputes this value from the stored accumulator, see REMAKE_ZC)
+            zn = make_float4(__builtin_fmaf(k.x, hdt, z0.x), __builtin_fmaf(k.y, hdt, z0.y), __builtin_fmaf(k.z, hdt, z0.z), __builtin_fmaf(k.w, hdt, z0.w));
+        } else if (stage < 3) {
+            const float4 ac = q2[sl];
+            acc = make_float4(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y, ac.z + 2.0f * k.z, ac.w + 2.0f * k.w);
+            zn = make_float4(z0.x + k.x * hdt, z0.y + k.y * hdt, z0.z + k.z * hdt, z0.w + k.w * hdt);
+        } else {
+            const float4 ac = q2[sl];
+            acc = ac;
+            zn = make_float4(z0.x + (ac.x + k.x) * dt / 6.0f, z0.y + (ac.y + k.y) * dt / 6.0f,
+                             z0.z + (ac.z + k.z) * dt / 6.0f, z0.w + (ac.w + k.w) * dt / 6.0f);
         }
-    };
-    if (!PRIME) load_batch(0);
-#pragma unroll
-    for (int b = 0; b < (PRIME ? 0 : NBATCH); ++b) {
-        float4 accn[KB];
-#pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const int k3 = b * KB + j;
-            const int ik2 = w + 256 * k3 + 16 * l, ikx = nsub * ik2 + k1;
-            const float gx = gxt[l + 16 * w + 256 * k3];
-            const double kx2 = (double)gx * (double)gx;                      // fftwfop.cpp:42,45
-            const float lapa = (float)(-(kx2 + ky2a)), lapb = (float)(-(kx2 + ky2b));
-            const float mska = coef_mask(a.coef, ikx, ky0), mskb = coef_mask(a.coef, ikx, ky0 + 1);
-            const float4 z0 = q0[j];
-            const float4 zc = stage == 0 ? z0 : q1[j];
-            float4 k;
-            k.x = (v[0][k3].x + (zc.x * lapa) * nu) * mska; k.y = (v[0][k3].y + (zc.y * lapa) * nu) * mska;
-            k.z = (v[1][k3].x + (zc.z * lapb) * nu) * mskb; k.w = (v[1][k3].y + (zc.w * lapb) * nu) * mskb;
-            float4 acc, zn;
-            if (stage == 0) {
-                acc = k;
-                zn = make_float4(z0.x + k.x * hdt, z0.y + k.y * hdt, z0.z + k.z * hdt, z0.w + k.w * hdt);
-            } else if (stage < 3) {
-                const float4 ac = q2[j];
-                acc = make_float4(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y, ac.z + 2.0f * k.z, ac.w + 2.0f * k.w);
-                zn = make_float4(z0.x + k.x * hdt, z0.y + k.y * hdt, z0.z + k.z * hdt, z0.w + k.w * hdt);
-            } else {
-                const float4 ac = q2[j];
-                acc = ac;
-                zn = make_float4(z0.x + (ac.x + k.x) * dt / 6.0f, z0.y + (ac.y + k.y) * dt / 6.0f,
-                                 z0.z + (ac.z + k.z) * dt / 6.0f, z0.w + (ac.w + k.w) * dt / 6.0f);
-            }
-            accn[j] = acc;
-            v[0][k3] = cf_make(zn.x, zn.y); v[1][k3] = cf_make(zn.z, zn.w);
-        }
-        if (b + 1 < NBATCH) load_batch(b + 1);
-#pragma unroll
-        for (int j = 0; j < KB; ++j) accp[j] = accn[j];
-        store_batch(b);
+        v[0][k3] = cf_make(zn.x, zn.y); v[1][k3] = cf_make(zn.z, zn.w);
+        if (k3 + DEPTH < 16) load_k3(k3 + DEPTH);
+        if (stage < 3) { st4<CF_NT_ACC != 0>(AC + k3 * sstep + voff_s, acc); cf_st4(ZC + k3 * sstep, voff_s, zn); }
+        else cf_st4(ZO + k3 * sstep, voff_s, zn);
         CF_FENCE();
     }
 
@@ -344,8 +347,8 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
             const float gx = gxt[16 * w + 256 * k3 + lkx];
             if (psi) {                                // psi_c = invertLaplacian(vort_c)   main.cpp:179
                 const double kx2 = (double)gx * (double)gx;
-                const float lia = (nsub * (w + 256 * k3 + 16 * l) + k1 == 0 && ky0 == 0) ? 1.0f : (float)(-(kx2 + ky2a));
-                const float lib = (float)(-(kx2 + ky2b));
+                const float lia = (nsub * (w + 256 * k3 + 16 * l) + k1 == 0 && ky0 == 0) ? 1.0f : (float)(-(kx2 + ky2_of(gya)));
+                const float lib = (float)(-(kx2 + ky2_of(gyb)));
                 za = pada ? cf_make(0.f, 0.f) : cf_make(za.x / lia, za.y / lia);      // (-(kx^2 + 0) = 0 at kx = 0 in a padding column)
                 zb = padb ? cf_make(0.f, 0.f) : cf_make(zb.x / lib, zb.y / lib);
             }

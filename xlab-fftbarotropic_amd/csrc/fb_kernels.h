@@ -25,6 +25,7 @@ struct SpecCoef {
     const double *ky2;     // [P]
     double gws;            // generalized_wavenumber_square         fftwfop.cpp:57
     int nx, hy;            // hy = ny/2+1 (columns >= hy are padding)
+    int gws_i;             // ceil(gws): ii^2 + j^2 is an integer below 2^28, so  (double) r2 >= gws  <=>  r2 >= ceil(gws)
 };
 
 // laplacian_coe[i][j] = (float)-(kx2 + ky2)                         fftwfop.cpp:45
@@ -32,9 +33,9 @@ FB_DEV float coef_lap(const SpecCoef &c, int i, int j) { return (float)(-(c.kx2[
 // dealiasing_mask                                                    fftwfop.cpp:57-68
 FB_DEV float coef_mask(const SpecCoef &c, int i, int j)
 {
-    int ii = i < c.nx - i ? i : c.nx - i;
-    double r2 = (double)ii * (double)ii + (double)j * (double)j;
-    return (r2 >= c.gws || j >= c.hy) ? 0.0f : 1.0f;
+    const int ii = i < c.nx - i ? i : c.nx - i;
+    const int r2 = ii * ii + j * j;                    // exact: ii <= nx/2 <= 8192, j <= 8200 (the reference compares the same integers as doubles)
+    return (r2 >= c.gws_i || j >= c.hy) ? 0.0f : 1.0f;
 }
 
 // -------------------------------------------------------------------------------------------

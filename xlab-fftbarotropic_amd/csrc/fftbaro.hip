@@ -311,6 +311,7 @@ extern "C" int fb_synchronize(fb_ctx *c) { if (!c) return fail(FB_EINVAL, "ctx N
 static SpecCoef make_coef(const fb_ctx *c)
 {
     SpecCoef s; s.gx = c->d_gx; s.kx2 = c->d_kx2; s.gy = c->d_gy; s.ky2 = c->d_ky2; s.gws = c->gws; s.nx = c->nx; s.hy = c->hy;
+    s.gws_i = c->gws >= 2147483647.0 ? 2147483647 : (int)ceil(c->gws);
     return s;
 }
 
