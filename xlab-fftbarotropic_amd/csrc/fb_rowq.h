@@ -32,6 +32,9 @@ struct RowQTw { cf w0[7], w1[3]; const cf *w2; };              // W_2048^{p t}, 
 // may go on to the wave-private exchanges without another barrier.
 template <class F> FB_DEV void rq_xch_group_bwd(cf *v, cf *xbuf, int w, int l, F &&behind_barrier)
 {
+#ifdef FB_R8_NOXG   /* timing experiment only */
+    behind_barrier(); return;
+#endif
     // no barrier in front: the slices were last read by the previous transform's wave-private exchanges, and the caller has passed the
     // staging barriers of this phase since
 #pragma unroll
@@ -44,6 +47,9 @@ template <class F> FB_DEV void rq_xch_group_bwd(cf *v, cf *xbuf, int w, int l, F
 // forward direction: the inverse permutation (register (q, h) of wave w is element p = w + 4 h of wave q)
 FB_DEV void rq_xch_group_fwd(cf *v, cf *xbuf, int w, int l)
 {
+#ifdef FB_R8_NOXG   /* timing experiment only */
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) lds_wr(&xbuf[w * RowQ::SLICE + j * 64 + l], v[j]);          // own slice: no barrier needed before
     lds_barrier();
@@ -114,6 +120,10 @@ FB_DEV void rq_dma_issue(cf *stg, int t, const RowView &view, int field, int row
 FB_DEV void rq_ext(cf *v, int t, const cf *stg, cf wx /* exp(+2 pi i t/N) */)
 {
     constexpr int M = RowQ::M;
+#ifdef FB_R8_NOEXT  /* timing experiment only */
+    for (int e = 0; e < 8; ++e) v[e] = cf_make(1.f + e, 1.f + t);
+    return;
+#endif
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int k = t + 256 * e;
@@ -173,7 +183,11 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const cf *__restrict
     __syncthreads();
 
     const int iters = (a.nx + gridDim.x - 1) / gridDim.x;
+#ifdef FB_ROW_SAMEROW   /* timing experiment only: every workgroup works on row 0 (no HBM traffic); results are wrong */
+    auto row_of = [&](int it, bool &valid) { const int r = it * gridDim.x + blockIdx.x; valid = r < a.nx; return a.x0; };
+#else
     auto row_of = [&](int it, bool &valid) { const int r = it * gridDim.x + blockIdx.x; valid = r < a.nx; return a.x0 + (valid ? r : 0); };
+#endif
     if (iters > 0) {
         bool vld; const int x = row_of(0, vld);
         rq_dma_issue<SLAB>(stg, t, a.M, 0, x);
@@ -227,7 +241,11 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const cf *__restrict
 #pragma unroll
         for (int e = 4; e < 8; ++e) lds_wr(&xbuf[tt + 256 * (e - 4)], v[e]);          // W[k], k >= M/2, at k - M/2
         lds_barrier();
+#ifdef FB_R8_NOST   /* timing experiment only: (almost) no stores */
+        if (valid && v[0].x == 123.456f) {
+#else
         if (valid) {
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int k = tt + 256 * e;                           // 0 <= k < M/2
