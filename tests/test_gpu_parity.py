@@ -658,9 +658,10 @@ def test_single_pass_8192_matches_three_kernel_path_and_oracle(O, R):
 
 
 def test_stage1_state_recompute_is_bitwise_neutral(tmp_path):
-    """k_col_full's stage 1 does not read the stage state back but forms it again as fma(rk1, dt/2, vort_c0) from the accumulator
-    that stage 0 stored (fb_col_full.h, REMAKE_ZC).  A library built with -DCF_REMAKE_ZC=0 (the state is read back) must give the
-    same bits after 2 steps of a noisy 4096^2 state (tools/cmp_variants.py runs each build in its own process)."""
+    """Stage 1 of k_col_full and of k_col_mid does not read the stage state back but forms it again as fma(rk1, dt/2, vort_c0) from
+    the accumulator that stage 0 stored (fb_col_full.h REMAKE_ZC, fb_kernels.h FB_MID_REMAKE_ZC).  A library built with both switched
+    off (the state is read back) must give the same bits: 2 steps of a noisy 4096^2 state on the default path, 3 steps at 2048^2 and
+    at 4096^2 with FB_FULL_PASS=0 on the three-kernel path (tools/cmp_variants.py runs each build in its own process)."""
     import shutil
     import subprocess
     import sys
@@ -669,11 +670,14 @@ def test_stage1_state_recompute_is_bitwise_neutral(tmp_path):
     root = os.path.dirname(HERE)
     alt = os.path.join(root, "xlab-fftbarotropic_amd", "lib", "alt_nozc_test.so")
     try:
-        subprocess.check_call([os.path.join(root, "tools", "build_variant.sh"), "nozc_test", "-DCF_REMAKE_ZC=0"], timeout=900)
-        out = subprocess.run([sys.executable, os.path.join(root, "tools", "cmp_variants.py"), alt, "4096", "2"], stdout=subprocess.PIPE,
-                             stderr=subprocess.PIPE, text=True, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        assert out.stdout.count("bitwise equal") == 2, out.stdout
+        subprocess.check_call([os.path.join(root, "tools", "build_variant.sh"), "nozc_test", "-DCF_REMAKE_ZC=0", "-DFB_MID_REMAKE_ZC=0"], timeout=900)
+        for n, steps, env in ((4096, 2, {}), (2048, 3, {}), (4096, 2, {"FB_FULL_PASS": "0"})):
+            e = dict(os.environ)
+            e.update(env)
+            out = subprocess.run([sys.executable, os.path.join(root, "tools", "cmp_variants.py"), alt, str(n), str(steps)], stdout=subprocess.PIPE,
+                                 stderr=subprocess.PIPE, text=True, timeout=600, env=e)
+            assert out.returncode == 0, out.stderr[-2000:]
+            assert out.stdout.count("bitwise equal") == 2, (n, env, out.stdout)
     finally:
         if os.path.exists(alt):
             os.remove(alt)

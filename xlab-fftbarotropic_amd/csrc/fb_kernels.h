@@ -573,6 +573,9 @@ __global__ void __launch_bounds__(256) k_col_block(ColArgs a)
 // fused middle kernel: [forward block sub-pass of the tendency] + viscous term + mask + RK4
 // update + the four spectral derivatives + [backward block sub-pass of each]
 // -------------------------------------------------------------------------------------------
+#ifndef FB_MID_REMAKE_ZC   /* 0: stage 1 reads its stage state back (A/B build for the bitwise test) */
+#define FB_MID_REMAKE_ZC 1
+#endif
 struct MidArgs {
     const cf *Tin;       // tendency after the strided forward sub-pass (mixed/partial layout)
     const cf *Zbase;     // vort_c0 of this step                    (private spectral layout)
@@ -657,8 +660,8 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
                     const float msk = coef_mask(a.coef, ikx, ky);
                     const cf zc = a.stage == 0 ? z0 : zcur;
                     cf k = cf_make((th[e].x + (zc.x * lap) * a.nu) * msk, (th[e].y + (zc.y * lap) * a.nu) * msk);
-                    if (a.stage == 0) {            // main.cpp:296
-                        acc = k; znew = cf_make(z0.x + k.x * (a.dt / 2.0f), z0.y + k.y * (a.dt / 2.0f));
+                    if (a.stage == 0) {            // main.cpp:296   (explicit fma: stage 1 forms this value again from the stored accumulator)
+                        acc = k; znew = cf_make(__builtin_fmaf(k.x, a.dt / 2.0f, z0.x), __builtin_fmaf(k.y, a.dt / 2.0f, z0.y));
                     } else if (a.stage == 1) {     // main.cpp:299
                         acc = cf_make(ac.x + 2.0f * k.x, ac.y + 2.0f * k.y);
                         znew = cf_make(z0.x + k.x * (a.dt / 2.0f), z0.y + k.y * (a.dt / 2.0f));
@@ -691,16 +694,24 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
                         for (int j = 0; j < JH; ++j) {
                             const int jp = hb * JH + j;
                             q0[j] = ld4<(FB_NT & 64) != 0>(reinterpret_cast<const float4 *>(a.Zbase) + sb + jp * 64);
+                            q1[j] = q2[j] = make_float4(0.f, 0.f, 0.f, 0.f);            // never looked at when masked, or at stage 0
                             if (!frozen[j] && a.stage != 0) {
-                                q1[j] = ld4<(FB_NT & 64) != 0>(reinterpret_cast<const float4 *>(a.Zcur) + sb + jp * 64);
                                 q2[j] = ld4<(FB_NT & 64) != 0>(reinterpret_cast<const float4 *>(a.Acc) + sb + jp * 64);
-                            } else q1[j] = q2[j] = make_float4(0.f, 0.f, 0.f, 0.f);   // never looked at: masked, or stage 0
+                                // stage 1 does not read its stage state back: stage 0 stored fma(rk1, dt/2, vort_c0) and, next to it, rk1 as
+                                // the accumulator -- the same instruction on the same bits gives it again (as in k_col_full)
+                                if (a.stage != 1 || !FB_MID_REMAKE_ZC) q1[j] = ld4<(FB_NT & 64) != 0>(reinterpret_cast<const float4 *>(a.Zcur) + sb + jp * 64);
+                            }
                         }
 #pragma unroll
                         for (int j = 0; j < JH; ++j) {
                             const int e = 2 * (hb * JH + j);
                             cf acc0, acc1;
-                            const float4 zq = frozen[j] ? q0[j] : q1[j];
+                            float4 zq = frozen[j] ? q0[j] : q1[j];
+                            if (FB_MID_REMAKE_ZC && !frozen[j] && a.stage == 1) {
+                                const float hd = a.dt / 2.0f;
+                                zq = make_float4(__builtin_fmaf(q2[j].x, hd, q0[j].x), __builtin_fmaf(q2[j].y, hd, q0[j].y),
+                                                 __builtin_fmaf(q2[j].z, hd, q0[j].z), __builtin_fmaf(q2[j].w, hd, q0[j].w));
+                            }
                             update(e, cf_make(q0[j].x, q0[j].y), cf_make(zq.x, zq.y), cf_make(q2[j].x, q2[j].y), acc0, zn[e]);
                             update(e + 1, cf_make(q0[j].z, q0[j].w), cf_make(zq.z, zq.w), cf_make(q2[j].z, q2[j].w), acc1, zn[e + 1]);
                             q2[j] = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
