@@ -21,6 +21,9 @@
 #pragma once
 #include "fb_row8.h"
 
+#ifndef RH_NT      /* nontemporal hint on the LDS-DMA loads of the four fields (as RQ_NT in fb_rowq.h) */
+#define RH_NT 0
+#endif
 template <int V> struct RowH {
     static constexpr int M = 4096 * V, N = 2 * M, T = 512;
     static constexpr int SLICE = Row8::SLICE;                  // complex per (wave, sub-sequence) slice of the exchange buffer
@@ -146,7 +149,7 @@ FB_DEV void rh_dma_issue(cf *stg, int t, const RowView &view, int field, int row
     for (int c = 0; c < 4 * V; ++c) {                 // 32 V chunks of 1 KiB, 4 V per wave
         const int ch = w + c * 8, k = ch * 128 + lane * 2;
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(view, field, row, k),
-                                         rh_to_lds(stg + ch * 128), 16, 0, 0);
+                                         rh_to_lds(stg + ch * 128), 16, 0, RH_NT ? 2 : 0);
     }
     // X[M]: one dword per lane (lanes 0, 1)
     rh_lds_ptr nyq = rh_to_lds(stg + M);

@@ -17,6 +17,10 @@
 #pragma once
 #include "fb_rowh.h"
 
+#ifndef RQ_NT      /* nontemporal hint: 1 = the LDS-DMA loads of the four fields (read once: streamed, they leave the tendency rows in the caches for
+                      k_col_full -- row pass -1.6 %, k_col_full -1.7 %), 2 = the tendency stores (k_col_full +1 %) */
+#define RQ_NT 1
+#endif
 struct RowQ {
     static constexpr int M = 2048, N = 4096, T = 256;
     static constexpr int SLICE = Row8::SLICE;                  // per-wave slice of the exchange buffer (A/B exchanges)
@@ -110,7 +114,7 @@ FB_DEV void rq_dma_issue(cf *stg, int t, const RowView &view, int field, int row
 #pragma unroll
     for (int c = 0; c < 4; ++c) {                     // 16 chunks of 1 KiB, 4 per wave
         const int ch = w + c * 4, k = ch * 128 + lane * 2;
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(view, field, row, k), rh_to_lds(stg + ch * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)row_ptr<SLAB>(view, field, row, k), rh_to_lds(stg + ch * 128), 16, 0, (RQ_NT & 1) ? 2 : 0);
     }
     rh_lds_ptr nyq = rh_to_lds(stg + M);              // X[M]: one dword per lane (lanes 0, 1)
     const float *src = reinterpret_cast<const float *>(row_ptr<SLAB>(view, field, row, M)) + (t & 1);
@@ -263,9 +267,9 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const cf *__restrict
                 case 1: co = mul_w16<1, -1>(co); break; case 2: co = mul_w16<2, -1>(co); break; case 3: co = mul_w16<3, -1>(co); break;
                 default: break;
                 }
-                if (row_keep<SLAB>(a.T, a.t_frozen, k)) st2<false>(const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x, k)), cadd(ev, co));
+                if (row_keep<SLAB>(a.T, a.t_frozen, k)) st2<(RQ_NT & 2) != 0>(const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x, k)), cadd(ev, co));
                 const cf tm = csub(ev, co);
-                if (row_keep<SLAB>(a.T, a.t_frozen, M - k)) st2<false>(const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x, M - k)), cf_make(tm.x, -tm.y));
+                if (row_keep<SLAB>(a.T, a.t_frozen, M - k)) st2<(RQ_NT & 2) != 0>(const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x, M - k)), cf_make(tm.x, -tm.y));
             }
             if (tt == 0 && row_keep<SLAB>(a.T, a.t_frozen, M / 2)) {
                 const cf wh = v[4];
