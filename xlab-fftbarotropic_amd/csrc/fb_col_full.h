@@ -190,8 +190,14 @@ FB_DEV void cf_st4(void *ubase, unsigned voff, float4 x) { *reinterpret_cast<flo
 #ifndef CF_NT_W4
 #define CF_NT_W4 1     /* measured: 0.192 -> 0.166 ms per launch, and the row pass that follows 0.094 -> 0.087 ms */
 #endif
-#ifndef CF_NT_TIN      /* tendency rows (read once) */
-#define CF_NT_TIN 0
+#ifndef CF_NT_TIN      /* tendency rows (read once): -1.8 % per launch at 4096^2, -1.6 % at 8192^2 (no gain in round 1, before the other streams were sorted out) */
+#define CF_NT_TIN 1
+#endif
+#ifndef CF_NT_Z0       /* vort_c0 (read once per stage): neutral to slightly worse */
+#define CF_NT_Z0 0
+#endif
+#ifndef CF_NT_RR3      /* the last of the three re-reads of the new state: -1 % alone, nothing on top of CF_NT_TIN */
+#define CF_NT_RR3 0
 #endif
 #ifndef CF_NT_ACC      /* RK accumulator (next touched a whole stage later) */
 #define CF_NT_ACC 1
@@ -281,7 +287,7 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
     float4 q0[DEPTH], q1[DEPTH], q2[DEPTH];
     auto load_k3 = [&](int k3) {
         const int sl = k3 % DEPTH;
-        q0[sl] = cf_ld4(Z0 + k3 * sstep, voff_s);
+        q0[sl] = ld4<CF_NT_Z0 != 0>(Z0 + k3 * sstep + voff_s);
         if (stage != 0) q2[sl] = ld4<CF_NT_ACC != 0>(AC + k3 * sstep + voff_s);
         if (stage != 0 && !REMAKE_ZC) q1[sl] = cf_ld4(ZC + k3 * sstep, voff_s);
     };
@@ -335,7 +341,7 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
             const unsigned vs = (unsigned)launder((int)voff_s);
 #pragma unroll
             for (int k3 = 0; k3 < 16; ++k3) {
-                const float4 z = cf_ld4(ZN + k3 * sstep, vs);
+                const float4 z = (CF_NT_RR3 && f == 3) ? ld4<true>(ZN + k3 * sstep + vs) : cf_ld4(ZN + k3 * sstep, vs);
                 v[0][k3] = cf_make(z.x, z.y); v[1][k3] = cf_make(z.z, z.w);
             }
         }
