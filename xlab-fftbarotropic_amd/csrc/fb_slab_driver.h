@@ -85,7 +85,7 @@ extern "C" int fb_slab_destroy(fb_slab *s)
 {
     if (!s) return FB_OK;
     if (s->comp) hipStreamSynchronize(s->comp);
-    if (s->comm) hipStreamSynchronize(s->comm);
+    if (s->comm && s->comm != s->comp) hipStreamSynchronize(s->comm);
     if (s->connected && s->tp.destroy) s->tp.destroy(s->tp.self);
     if (s->m) fb_model_destroy(s->m);
     if (s->c) fb_destroy(s->c);
@@ -93,7 +93,7 @@ extern "C" int fb_slab_destroy(fb_slab *s)
     for (hipEvent_t *e : evs) if (*e) hipEventDestroy(*e);
     for (auto &e : s->ev_f) if (e) hipEventDestroy(e);
     for (auto &e : s->ev_r) if (e) hipEventDestroy(e);
-    if (s->owns_streams) { if (s->comp) hipStreamDestroy(s->comp); if (s->comm) hipStreamDestroy(s->comm); }
+    if (s->owns_streams) { if (s->comm && s->comm != s->comp) hipStreamDestroy(s->comm); if (s->comp) hipStreamDestroy(s->comp); }
     delete s;
     return FB_OK;
 }
@@ -117,6 +117,13 @@ extern "C" int fb_slab_create(fb_slab **out, int nx, int ny, float lx, float ly,
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(FB_EHIP, "fb_slab_create: cannot create events"));
     if ((rc = model_create_impl(&s->m, s->c, nu, dt, true))) return bail(rc);
     slab_plan(nx, ny, world, &s->nfg, &s->nch);
+    // Nothing to overlap when a stage has one field group and one row chunk (small slabs): the exchanges then go on the compute
+    // stream, in order, and the stage has no cross-stream hand-overs (each costs the GPU ~10-15 us of idling; tools/slab_local_time.py:
+    // rank-local 4096^2 step on 8 ranks 0.47 -> 0.3x ms).  FB_SLAB_TWO_STREAMS=1 keeps the separate communication stream.
+    if (s->nfg == 1 && s->nch == 1 && !getenv("FB_SLAB_TWO_STREAMS")) {
+        hipStreamDestroy(s->comm);
+        s->comm = s->comp;
+    }
     s->connected = world == 1;                             // nothing to connect on one rank
     *out = s;
     return FB_OK;
@@ -204,6 +211,7 @@ extern "C" int fb_slab_transport_selftest(fb_slab *s, size_t count, size_t *wron
 // ---- stream plumbing ----
 static int slab_after(hipStream_t waiter, hipStream_t producer, hipEvent_t ev)      // `waiter` continues behind what `producer` has queued so far
 {
+    if (waiter == producer) return FB_OK;                 // one stream: it does anyway
     HIPCHK(hipEventRecord(ev, producer));
     HIPCHK(hipStreamWaitEvent(waiter, ev, 0));
     return FB_OK;
@@ -327,7 +335,7 @@ static int slab_stage(fb_slab *s, int stage)
         if ((rc = model_col_bwd_active(m, f0, f1))) return rc;
         if (c->world > 1) {
             if ((rc = slab_after(s->comm, s->comp, s->ev_f[g]))) return rc;
-            if (g == 0) HIPCHK(hipStreamWaitEvent(s->comm, s->ev_rows_done, 0));          // the previous stage's row pass is done reading w4_recv
+            if (g == 0 && s->comm != s->comp) HIPCHK(hipStreamWaitEvent(s->comm, s->ev_rows_done, 0));   // the previous stage's row pass is done reading w4_recv
             if ((rc = slab_xchg(s, B.w4_send, B.w4_recv, 4 * fld, f0 * fld, (f1 - f0) * fld))) return rc;
         }
     }
@@ -339,15 +347,15 @@ static int slab_stage(fb_slab *s, int stage)
         if ((rc = launch_row<ROW_FUSED>(c, fused_row_args(m, h * rows, rows)))) return rc;
         if (c->world > 1) {
             if ((rc = slab_after(s->comm, s->comp, s->ev_r[h]))) return rc;
-            if (h == 0) HIPCHK(hipStreamWaitEvent(s->comm, s->ev_fwd_done, 0));           // the previous forward pass is done with t_recv
+            if (h == 0 && s->comm != s->comp) HIPCHK(hipStreamWaitEvent(s->comm, s->ev_fwd_done, 0));    // the previous forward pass is done with t_recv
             if ((rc = slab_xchg(s, B.t_send, B.t_recv, fld, (size_t)h * rows * c->grp[0].ncols, (size_t)rows * c->grp[0].ncols))) return rc;
         }
     }
-    HIPCHK(hipEventRecord(s->ev_rows_done, s->comp));
+    if (s->comm != s->comp) HIPCHK(hipEventRecord(s->ev_rows_done, s->comp));
     if (c->world > 1 && (rc = slab_after(s->comp, s->comm, s->ev_t))) return rc;
     // forward x pass, viscosity, mask, RK stage update, derivatives of the new stage state (main.cpp:148,179-212,237-251,296-312)
     if ((rc = model_col_fwd(m, stage))) return rc;
-    HIPCHK(hipEventRecord(s->ev_fwd_done, s->comp));
+    if (s->comm != s->comp) HIPCHK(hipEventRecord(s->ev_fwd_done, s->comp));
     return FB_OK;
 }
 
