@@ -196,6 +196,9 @@ FB_DEV void cf_st4(void *ubase, unsigned voff, float4 x) { *reinterpret_cast<flo
 #ifndef CF_NT_Z0       /* vort_c0 (read once per stage): neutral to slightly worse */
 #define CF_NT_Z0 0
 #endif
+#ifndef CF_NT_ZC       /* the previous stage state, read by stages 2 and 3 for the viscous term */
+#define CF_NT_ZC 0
+#endif
 #ifndef CF_NT_RR3      /* the last of the three re-reads of the new state: -1 % alone, nothing on top of CF_NT_TIN */
 #define CF_NT_RR3 0
 #endif
@@ -289,7 +292,7 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
         const int sl = k3 % DEPTH;
         q0[sl] = ld4<CF_NT_Z0 != 0>(Z0 + k3 * sstep + voff_s);
         if (stage != 0) q2[sl] = ld4<CF_NT_ACC != 0>(AC + k3 * sstep + voff_s);
-        if (stage != 0 && !REMAKE_ZC) q1[sl] = cf_ld4(ZC + k3 * sstep, voff_s);
+        if (stage != 0 && !REMAKE_ZC) q1[sl] = ld4<CF_NT_ZC != 0>(ZC + k3 * sstep + voff_s);
     };
     if (!PRIME) {
 #pragma unroll

@@ -171,6 +171,18 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const cf *__restrict
     cf *xbuf = reinterpret_cast<cf *>(smem_raw);
     cf *stg = xbuf + RowQ::XBUF;
     const int t = threadIdx.x, l = t & 63;
+    const int iters = (a.nx + gridDim.x - 1) / gridDim.x;
+#ifdef FB_ROW_SAMEROW   /* timing experiment only: every workgroup works on row 0 (no HBM traffic); results are wrong */
+    auto row_of = [&](int it, bool &valid) { const int r = it * gridDim.x + blockIdx.x; valid = r < a.nx; return a.x0; };
+#else
+    auto row_of = [&](int it, bool &valid) { const int r = it * gridDim.x + blockIdx.x; valid = r < a.nx; return a.x0 + (valid ? r : 0); };
+#endif
+    // One workgroup per row: its start-up is on the critical path 4096 times per launch.  The first field's row is sent for BEFORE the
+    // twiddle tables are read, so that the two round trips to memory overlap (vmcnt retires in order: the tables' arrival implies the row's).
+    if (iters > 0) {
+        bool vld; const int x = row_of(0, vld);
+        rq_dma_issue<SLAB>(stg, t, a.M, 0, x);
+    }
     RowQTw tw;
 #pragma unroll
     for (int p = 1; p < 8; ++p) tw.w0[p - 1] = root2048[p * t];
@@ -182,21 +194,11 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const cf *__restrict
     cf wx;
     { const cf r = rootN[t]; wx = cf_make(r.x, -r.y); }                               // exp(+2 pi i t/4096)
 #pragma unroll
-    for (int p = 0; p < 7; ++p) asm volatile("" :: "v"(tw.w0[p]));                    // land the table loads here, not behind a prefetch
+    for (int p = 0; p < 7; ++p) asm volatile("" :: "v"(tw.w0[p]));                    // land the table loads here, not behind a later prefetch
     asm volatile("" :: "v"(tw.w1[0]), "v"(tw.w1[1]), "v"(tw.w1[2]), "v"(wx));
+    RH_WAIT_ROW();
     __syncthreads();
 
-    const int iters = (a.nx + gridDim.x - 1) / gridDim.x;
-#ifdef FB_ROW_SAMEROW   /* timing experiment only: every workgroup works on row 0 (no HBM traffic); results are wrong */
-    auto row_of = [&](int it, bool &valid) { const int r = it * gridDim.x + blockIdx.x; valid = r < a.nx; return a.x0; };
-#else
-    auto row_of = [&](int it, bool &valid) { const int r = it * gridDim.x + blockIdx.x; valid = r < a.nx; return a.x0 + (valid ? r : 0); };
-#endif
-    if (iters > 0) {
-        bool vld; const int x = row_of(0, vld);
-        rq_dma_issue<SLAB>(stg, t, a.M, 0, x);
-        RH_WAIT_ROW();
-    }
     for (int it = 0; it < iters; ++it) {
         bool valid;
         const int x = row_of(it, valid);                              // an invalid workgroup recomputes row 0, stores nothing
