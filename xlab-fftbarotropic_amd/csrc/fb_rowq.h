@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) k_rowq_permute_src(const float *__restric
 }
 
 template <bool SLAB>
-__global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const cf *__restrict__ root2048 /* W_2048^j */, const cf *__restrict__ rootN /* W_4096^j */)
+__global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__restrict__ tab /* per-thread twiddles, [6][256] float4: make_rowq_table() */)
 {
     constexpr int M = RowQ::M;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -183,16 +183,23 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const cf *__restrict
         bool vld; const int x = row_of(0, vld);
         rq_dma_issue<SLAB>(stg, t, a.M, 0, x);
     }
+    // this thread's twiddles, one coalesced table (six 16-byte loads; gathered from the root tables they were twelve loads that
+    // touched up to 28 cache lines per wave instruction):  W_2048^{p t} (p = 1..7), W_256^{q l} (q = 1..3), W_4096^{t}, and for t < 64
+    // the LDS table entry W_64^{p l_lo} at [p = t >> 3][l_lo = t & 7]
     RowQTw tw;
-#pragma unroll
-    for (int p = 1; p < 8; ++p) tw.w0[p - 1] = root2048[p * t];
-#pragma unroll
-    for (int q = 1; q < 4; ++q) tw.w1[q - 1] = root2048[8 * q * l];                   // W_256^{q l} = W_2048^{8 q l}
-    cf *tw2 = stg + RowQ::STG;
-    if (t < 64) tw2[t] = root2048[32 * (t & 7) * (t >> 3)];                           // W_64^{p l_lo} = W_2048^{32 p l_lo} at [p][l_lo]
-    tw.w2 = tw2;
     cf wx;
-    { const cf r = rootN[t]; wx = cf_make(r.x, -r.y); }                               // exp(+2 pi i t/4096)
+    cf *tw2 = stg + RowQ::STG;
+    {
+        float4 q[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) q[j] = tab[j * 256 + t];
+        tw.w0[0] = cf_make(q[0].x, q[0].y); tw.w0[1] = cf_make(q[0].z, q[0].w); tw.w0[2] = cf_make(q[1].x, q[1].y); tw.w0[3] = cf_make(q[1].z, q[1].w);
+        tw.w0[4] = cf_make(q[2].x, q[2].y); tw.w0[5] = cf_make(q[2].z, q[2].w); tw.w0[6] = cf_make(q[3].x, q[3].y);
+        tw.w1[0] = cf_make(q[3].z, q[3].w); tw.w1[1] = cf_make(q[4].x, q[4].y); tw.w1[2] = cf_make(q[4].z, q[4].w);
+        wx = cf_make(q[5].x, -q[5].y);                                                // exp(+2 pi i t/4096)
+        if (t < 64) tw2[t] = cf_make(q[5].z, q[5].w);
+    }
+    tw.w2 = tw2;
 #pragma unroll
     for (int p = 0; p < 7; ++p) asm volatile("" :: "v"(tw.w0[p]));                    // land the table loads here, not behind a later prefetch
     asm volatile("" :: "v"(tw.w1[0]), "v"(tw.w1[1]), "v"(tw.w1[2]), "v"(wx));

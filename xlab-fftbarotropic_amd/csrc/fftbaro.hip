@@ -95,7 +95,7 @@ struct fb_ctx {
     int rowh_v;                 // fused row pass of ny = 8192 (1) / 16384 (2) through k_rowh (FB_NO_ROWH=1: 0 = the Stockham kernel)
     cf *d_tw_4096;              // W_4096^j for k_rowh's sub-transforms
     bool use_rowq;              // fused row pass of ny = 4096 through k_rowq (one real row per 4-wave workgroup) instead of k_row8
-    cf *d_tw_2048;              // W_2048^j for k_rowq
+    cf *d_tw_2048;              // k_rowq's per-thread twiddle table (make_rowq_table)
     int pace_strided;           // pace the strided sub-pass's accesses (fields much larger than the caches)
     int col_chunks;             // x pass of a stage is issued in this many column chunks ...
     int col_streams;            // ... round-robin over this many streams, so that one chunk's kernel tails are filled by the next chunk
@@ -138,6 +138,23 @@ static std::vector<cf> make_root_table(int n)
         t[j].x = (float)cos(a); t[j].y = (float)sin(a);
     }
     return t;
+}
+
+// k_rowq's per-thread twiddles, [6][256] float4 = twelve complex per thread t (fb_rowq.h): W_2048^{p t} (p = 1..7), W_256^{q (t & 63)}
+// (q = 1..3), W_4096^{t}, and for t < 64 W_64^{(t >> 3)(t & 7)}; the very values of the root tables
+static std::vector<cf> make_rowq_table()
+{
+    const std::vector<cf> r2048 = make_root_table(2048), r4096 = make_root_table(4096);
+    std::vector<cf> tab(12 * 256);
+    for (int t = 0; t < 256; ++t) {
+        cf e[12];
+        for (int p = 1; p < 8; ++p) e[p - 1] = r2048[(p * t) % 2048];
+        for (int q = 1; q < 4; ++q) e[6 + q] = r2048[(8 * q * (t & 63)) % 2048];
+        e[10] = r4096[t];
+        e[11] = t < 64 ? r2048[(32 * (t & 7) * (t >> 3)) % 2048] : cf{0.f, 0.f};
+        for (int j = 0; j < 6; ++j) { tab[(j * 256 + t) * 2] = e[2 * j]; tab[(j * 256 + t) * 2 + 1] = e[2 * j + 1]; }
+    }
+    return tab;
 }
 
 // Stockham stage tables for a radix list walked in order (forward-sign values); layout must
@@ -282,7 +299,7 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
     c->rowh_v = (ny == 8192 || ny == 16384) && !getenv("FB_NO_ROWH") ? ny / 8192 : 0;
     if (c->rowh_v && (rc = upload(&c->d_tw_4096, make_root_table(4096)))) { fb_destroy(c); return rc; }
     { const char *e = getenv("FB_ROWQ"); c->use_rowq = ny == 4096 && !getenv("FB_NO_ROW8") && (e ? e[0] != '0' : FB_ROWQ_DEFAULT); }
-    if (c->use_rowq && (rc = upload(&c->d_tw_2048, make_root_table(2048)))) { fb_destroy(c); return rc; }
+    if (c->use_rowq && (rc = upload(&c->d_tw_2048, make_rowq_table()))) { fb_destroy(c); return rc; }
     hipDeviceProp_t prop;
     if (hipGetDevice(&c->dev) != hipSuccess || hipGetDeviceProperties(&prop, c->dev) != hipSuccess) {
         fb_destroy(c); return fail(FB_EHIP, "fb_create: cannot query the device");
@@ -555,7 +572,7 @@ static int launch_rowq(fb_ctx *c, const RowArgs &a)
     auto kern = c->world > 1 ? k_rowq<true> : k_rowq<false>;
     int rc = set_max_lds(c, (const void *)kern, RowQ::LDS_BYTES);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), RowQ::LDS_BYTES, c->stream, a, (const cf *)c->d_tw_2048, (const cf *)c->d_tw_row3);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), RowQ::LDS_BYTES, c->stream, a, (const float4 *)c->d_tw_2048);
     HIPCHK(hipGetLastError());
     return FB_OK;
 }
