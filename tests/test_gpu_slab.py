@@ -201,11 +201,15 @@ def test_config5_16384_source_forced_on_8_ranks_full_size():
 
 @pytest.mark.parametrize("n,world,steps,env", [(512, 4, 40, {"FB_SLAB_FIELD_GROUPS": "4", "FB_SLAB_ROW_CHUNKS": "2"}),
                                                (4096, 4, 8, {"FB_SLAB_FIELD_GROUPS": "4", "FB_SLAB_ROW_CHUNKS": "4"}),
-                                               (4096, 8, 6, None)])
+                                               (4096, 8, 6, None),
+                                               (4096, 8, 6, {"FB_SLAB_TWO_STREAMS": "1"}),
+                                               (512, 4, 40, None)])
 def test_engine_slab_many_steps_stay_in_step(n, world, steps, env):
     """Ranks racing through many stages (thousands of event hand-offs between up to 16 streams), on a small grid where the host
     runs far ahead of the device and at the headline grid where kernels take long enough for every overlap to happen: any missing
-    dependency between a rank's compute and communication streams shows up as a bit difference."""
+    dependency between a rank's compute and communication streams shows up as a bit difference.  Plans with one field group and one
+    row chunk (4096^2 on 8 ranks, 512^2 on 4) run on ONE stream per rank, the exchanges in line with the kernels;
+    FB_SLAB_TWO_STREAMS=1 keeps the separate communication stream for the same plan."""
     import xlab_fftbarotropic_amd as X
     v0 = X.make_field("kuo2004", n)
     dt = 3.0 if n <= 1024 else 0.75
