@@ -21,6 +21,16 @@
                       k_col_full -- row pass -1.6 %, k_col_full -1.7 %), 2 = the tendency stores (k_col_full +1 %) */
 #define RQ_NT 1
 #endif
+// Opaque thread id per phase (launder): fewer live registers, but every phase recomputes its LDS addresses.  The one-GPU kernel has
+// the registers (128 of 128, 8 B of scratch) and does without -- 217 of 381 non-packed vector instructions per row gone, -2.5 % per launch;
+// the slab-blocked instance would spill 356 B per lane and keeps it.  RQ_LAUNDER_MODE: 3 = always, 0 = never, unset = by instance.
+#ifdef RQ_LAUNDER_MODE
+#define RQ_LAUNDER(t) ((RQ_LAUNDER_MODE & 2) ? launder(t) : (t))
+#define RQ_LAUNDER2(t) ((RQ_LAUNDER_MODE & 1) ? launder(t) : (t))
+#else
+#define RQ_LAUNDER(t) (SLAB ? launder(t) : (t))
+#define RQ_LAUNDER2(t) (SLAB ? launder(t) : (t))
+#endif
 struct RowQ {
     static constexpr int M = 2048, N = 4096, T = 256;
     static constexpr int SLICE = Row8::SLICE;                  // per-wave slice of the exchange buffer (A/B exchanges)
@@ -213,7 +223,7 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__rest
         const int xn = (it + 1 < iters) ? row_of(it + 1, vn) : -1;
         cf v[8], p[8];
         auto c2r_phase = [&](bool wait, int next_field, int next_row) {
-            const int tp = launder(t);
+            const int tp = RQ_LAUNDER(t);
             if (wait) RH_WAIT_ROW();
             lds_barrier();
             rq_ext(v, tp, stg, wx);
@@ -242,7 +252,7 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__rest
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = cf_make(p[e].x - (v[e].x * a.scale) * zy[e].x, p[e].y - (v[e].y * a.scale) * zy[e].y);   // main.cpp:214,225-227
         }
-        const int tt = launder(t);
+        const int tt = RQ_LAUNDER2(t);
         if (a.src) {                                                  // + vort_src (permuted order)
             const float2 *sp = reinterpret_cast<const float2 *>(a.src) + (size_t)x * M + tt;
 #pragma unroll
