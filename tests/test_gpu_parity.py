@@ -506,7 +506,7 @@ def _noise_run(env, steps, tmpdir, tag):
     import subprocess
     import sys
     e = dict(os.environ)
-    for k in ("FB_FULL_PASS", "FB_FULL_NOSKIP", "FB_NO_COLUMN_SKIP", "FB_NO_ROW8", "FB_ROWQ", "FB_PITCH_EXTRA", "FB_PITCH_TUNE", "FB_NO_PITCH_TUNE"):
+    for k in ("FB_FULL_PASS", "FB_FULL_NOSKIP", "FB_NO_COLUMN_SKIP", "FB_NO_ROW8", "FB_ROWQ", "FB_PITCH_EXTRA", "FB_PITCH_TUNE", "FB_NO_PITCH_TUNE", "FB_NO_PRESCALE"):
         e.pop(k, None)
     e.update(env)
     out = os.path.join(tmpdir, tag + ".npz")
@@ -530,9 +530,12 @@ def test_frozen_mode_shortcuts_are_bitwise_neutral_4096(O, R):
         # the row pitch of the private arrays is a performance knob only: the minimal pitch and the probed one give the same bits
         full_p0 = _noise_run({"FB_PITCH_EXTRA": "0"}, steps, d, "full_p0")
         full_pt = _noise_run({"FB_PITCH_TUNE": "1"}, steps, d, "full_pt")
+        # k_col_full hands the four fields over multiplied by 1/GRIDS (a power of two) and k_rowq skips its own normalisation: exact
+        full_ns2 = _noise_run({"FB_NO_PRESCALE": "1"}, steps, d, "full_noprescale")
     for k in ("vort", "spec", "u", "psi"):
         assert np.array_equal(full[k].view(np.uint32), full_p0[k].view(np.uint32)), k
         assert np.array_equal(full[k].view(np.uint32), full_pt[k].view(np.uint32)), k
+        assert np.array_equal(full[k].view(np.uint32), full_ns2[k].view(np.uint32)), k
         assert np.array_equal(three[k].view(np.uint32), three_ns[k].view(np.uint32)), k
         assert np.array_equal(full[k].view(np.uint32), full_ns[k].view(np.uint32)), k
         assert R.rel_l2(full[k].view(np.float32), three[k].view(np.float32)) < 2e-6, k

@@ -61,6 +61,8 @@ struct FullArgs {
     const cf *tw256;      // W256^m, m < 256
     const cf *tw4096;     // W4096^m (first 256 entries used)
     long sub_rows;        // rows of the mixed arrays per sub-sequence (4096)
+    float wscale;         // the derivative fields leave multiplied by this: 1, or 1/GRIDS (a power of two: exact) when the row pass
+                          // that reads them skips its own /GRIDS (k_rowq<false, true>; main.cpp:154-214 normalise after the c2r)
 };
 
 // 16x16 transpose between the wave index and the register index (one column = 8 B per lane)
@@ -361,7 +363,7 @@ __global__ void __launch_bounds__(CF_THREADS) k_col_full(FullArgs a)
                 za = pada ? cf_make(0.f, 0.f) : cf_make(za.x / lia, za.y / lia);      // (-(kx^2 + 0) = 0 at kx = 0 in a padding column)
                 zb = padb ? cf_make(0.f, 0.f) : cf_make(zb.x / lib, zb.y / lib);
             }
-            const float ka = use_gx ? gx : gya, kb = use_gx ? gx : gyb;
+            const float ka = (use_gx ? gx : gya) * a.wscale, kb = (use_gx ? gx : gyb) * a.wscale;
             v[0][k3] = cf_make(-za.y * ka, za.x * ka);
             v[1][k3] = cf_make(-zb.y * kb, zb.x * kb);
             CF_FENCE();

@@ -179,6 +179,7 @@ struct RowArgs {
     float *rout;            // real output [x][y]                                   (INV)
     int x0, nx;             // local rows [x0, x0 + nx), nx even (a row chunk of the pipelined multi-GPU step, else everything)
     float scale;            // 1/GRIDS (FUSED) ; 1/GRIDS or 1 (INV)
+    int prescaled;          // FUSED, k_rowq on one GPU: the four fields arrive multiplied by 1/GRIDS already (FullArgs::wscale)
     const cf *tw_bwd, *tw_fwd;
     // k_rowh2 (nx = 8192 with the radix-2 x step fused into the row pass, fb_col_full.h): rows per sub-sequence and W_nx^j
     long sub_rows;

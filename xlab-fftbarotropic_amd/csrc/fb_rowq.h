@@ -173,7 +173,9 @@ __global__ void __launch_bounds__(256) k_rowq_permute_src(const float *__restric
     }
 }
 
-template <bool SLAB>
+// PRE: the four fields arrive multiplied by 1/GRIDS (k_col_full, FullArgs::wscale): GRIDS is a power of two on this path, so the
+// scaling commutes exactly with every rounding of the transforms and the 32 multiplications per thread and row are not needed here
+template <bool SLAB, bool PRE = false>
 __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__restrict__ tab /* per-thread twiddles, [6][256] float4: make_rowq_table() */)
 {
     constexpr int M = RowQ::M;
@@ -239,18 +241,20 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__rest
         };
         c2r_phase(false, 2, x);                                       // d vort/dx                         main.cpp:154
 #pragma unroll
-        for (int e = 0; e < 8; ++e) p[e] = cf_make(v[e].x * a.scale, v[e].y * a.scale);
+        for (int e = 0; e < 8; ++e) p[e] = PRE ? v[e] : cf_make(v[e].x * a.scale, v[e].y * a.scale);
         c2r_phase(true, 1, x);                                        // d psi/dy: -u * dvortdx = (c2r * scale) * dvortdx   main.cpp:200-201,225
 #pragma unroll
-        for (int e = 0; e < 8; ++e) p[e] = cf_make((v[e].x * a.scale) * p[e].x, (v[e].y * a.scale) * p[e].y);
+        for (int e = 0; e < 8; ++e) p[e] = PRE ? cf_make(v[e].x * p[e].x, v[e].y * p[e].y) : cf_make((v[e].x * a.scale) * p[e].x, (v[e].y * a.scale) * p[e].y);
         c2r_phase(true, 3, x);                                        // d vort/dy                         main.cpp:168
         {
             cf zy[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) zy[e] = cf_make(v[e].x * a.scale, v[e].y * a.scale);
+            for (int e = 0; e < 8; ++e) zy[e] = PRE ? v[e] : cf_make(v[e].x * a.scale, v[e].y * a.scale);
             c2r_phase(true, 0, xn);                                   // d psi/dx; the next row's first field travels meanwhile
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = cf_make(p[e].x - (v[e].x * a.scale) * zy[e].x, p[e].y - (v[e].y * a.scale) * zy[e].y);   // main.cpp:214,225-227
+            for (int e = 0; e < 8; ++e)                               // main.cpp:214,225-227
+                v[e] = PRE ? cf_make(p[e].x - v[e].x * zy[e].x, p[e].y - v[e].y * zy[e].y)
+                           : cf_make(p[e].x - (v[e].x * a.scale) * zy[e].x, p[e].y - (v[e].y * a.scale) * zy[e].y);
         }
         const int tt = RQ_LAUNDER2(t);
         if (a.src) {                                                  // + vort_src (permuted order)

@@ -569,7 +569,7 @@ static int launch_rowq(fb_ctx *c, const RowArgs &a)
     // grid of 1024 looping over rows (the dispatcher's refill keeps the four contexts of a CU out of step; the prologue is cheap)
     int grid = a.nx;
     if (const char *e = getenv("FB_ROW_GRID")) { int v = atoi(e); if (v >= 64 && v < grid) grid = v; }
-    auto kern = c->world > 1 ? k_rowq<true> : k_rowq<false>;
+    auto kern = c->world > 1 ? k_rowq<true, false> : a.prescaled ? k_rowq<false, true> : k_rowq<false, false>;
     int rc = set_max_lds(c, (const void *)kern, RowQ::LDS_BYTES);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), RowQ::LDS_BYTES, c->stream, a, (const float4 *)c->d_tw_2048);
@@ -925,6 +925,7 @@ struct fb_model {
     // (2: the remaining radix-2 step of the x transform is fused into the row pass, k_rowh2)
     bool full;
     int nsub;
+    bool prescale;                   // k_col_full writes the derivative fields times 1/GRIDS and k_rowq<false, true> does not normalise (4096^2 on one GPU)
     // hipGraph replay of one RK4 step (launch-bound small grids): captured lazily on a non-null stream,
     // dropped whenever something baked into the kernel arguments changes (source pointer, stream)
     bool use_graph, warmed;
@@ -950,6 +951,7 @@ static int model_create_impl(fb_model **out, fb_ctx *c, float nu, float dt, bool
     (void)fp;
     m->nsub = phase_flow ? 0 : full_pass_nsub(c);
     m->full = m->nsub != 0;
+    m->prescale = m->full && c->world == 1 && c->use_rowq && !getenv("FB_NO_PRESCALE");      // use_rowq: ny == 4096, so GRIDS = nx * ny is a power of two
     int rc = FB_OK;
     auto alloc0 = [&](cf **p, size_t elems) {              // zero-initialised device array (pad columns stay zero: every pass is linear)
         if (rc || elems == 0) return;
@@ -1106,6 +1108,7 @@ static int launch_col_full(fb_model *m, int stage)
     a.Tin = B.t_recv; a.Zbase = B.ZA; a.Zcur = B.ZB; a.Acc = B.ACC; a.Zout = B.ZA; a.W4 = B.w4_send;
     a.fstride = (long)priv_elems(c); a.P = c->P; a.ntiles = (c->ny / 2) / 8; a.stage = stage; a.nu = m->nu; a.dt = m->dt;
     a.nsub = m->nsub; a.sub_rows = 4096;
+    a.wscale = m->prescale ? 1.0f / (float)((size_t)c->nx * c->ny) : 1.0f;
     a.ntiles_run = c->grp[0].nct_active * 2 < a.ntiles ? c->grp[0].nct_active * 2 : a.ntiles;   // 16-column tiles -> 8-column tiles
     if (getenv("FB_FULL_NOSKIP")) a.ntiles_run = a.ntiles;
     if (stage == 4) a.ntiles_run = a.ntiles + 1;
@@ -1154,7 +1157,7 @@ static RowArgs fused_row_args(fb_model *m, int x0, int nrows)
     RowArgs a = row_args_base(c);
     if (c->world == 1) { a.M = view_single(c, m->gb[0].w4_recv, (long)priv_elems(c)); a.T = view_single(c, m->gb[0].t_send, 0); }
     else { a.M = view_slab(c, m->gb[0].w4_recv, m->gb[1].w4_recv, 4); a.T = view_slab(c, m->gb[0].t_send, m->gb[1].t_send, 1); a.t_frozen = 0; }
-    a.src = m->src; a.scale = 1.0f / (float)((size_t)c->nx * c->ny); a.x0 = x0; a.nx = nrows;
+    a.src = m->src; a.scale = 1.0f / (float)((size_t)c->nx * c->ny); a.x0 = x0; a.nx = nrows; a.prescaled = m->prescale ? 1 : 0;
     return a;
 }
 // forward x pass of the tendency + RK stage update + derivatives of the new stage state (three-kernel path)
