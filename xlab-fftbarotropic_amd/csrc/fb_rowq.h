@@ -21,15 +21,16 @@
                       k_col_full -- row pass -1.6 %, k_col_full -1.7 %), 2 = the tendency stores (k_col_full +1 %) */
 #define RQ_NT 1
 #endif
-// Opaque thread id per phase (launder): fewer live registers, but every phase recomputes its LDS addresses.  The one-GPU kernel has
-// the registers (128 of 128, 8 B of scratch) and does without -- 217 of 381 non-packed vector instructions per row gone, -2.5 % per launch;
-// the slab-blocked instance would spill 356 B per lane and keeps it.  RQ_LAUNDER_MODE: 3 = always, 0 = never, unset = by instance.
+// Opaque thread id per phase (launder): fewer live registers, but every phase recomputes its LDS addresses.  With one row per workgroup
+// (no row loop to hoist things out of) every instance has the registers to do without: 217 of 381 non-packed vector instructions per row
+// gone, -2.5 % per launch on one GPU.  The looping slab-blocked instance would spill 356 B per lane and keeps it.
+// RQ_LAUNDER_MODE: 3 = always, 0 = never, unset = by instance.
 #ifdef RQ_LAUNDER_MODE
 #define RQ_LAUNDER(t) ((RQ_LAUNDER_MODE & 2) ? launder(t) : (t))
 #define RQ_LAUNDER2(t) ((RQ_LAUNDER_MODE & 1) ? launder(t) : (t))
 #else
-#define RQ_LAUNDER(t) (SLAB ? launder(t) : (t))
-#define RQ_LAUNDER2(t) (SLAB ? launder(t) : (t))
+#define RQ_LAUNDER(t) ((SLAB && LOOP) ? launder(t) : (t))
+#define RQ_LAUNDER2(t) ((SLAB && LOOP) ? launder(t) : (t))
 #endif
 struct RowQ {
     static constexpr int M = 2048, N = 4096, T = 256;
@@ -175,7 +176,10 @@ __global__ void __launch_bounds__(256) k_rowq_permute_src(const float *__restric
 
 // PRE: the four fields arrive multiplied by 1/GRIDS (k_col_full, FullArgs::wscale): GRIDS is a power of two on this path, so the
 // scaling commutes exactly with every rounding of the transforms and the 32 multiplications per thread and row are not needed here
-template <bool SLAB, bool PRE = false>
+// LOOP: a persistent grid, each workgroup loops over rows (FB_ROW_GRID experiments).  The default launch has one workgroup per row; with
+// the trip count known to be one the compiler no longer hoists the store offsets out of the row loop (which cost a spilled register whose
+// reload sat behind the first store: a wait for that store's acknowledgement in every workgroup).
+template <bool SLAB, bool PRE = false, bool LOOP = false>
 __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__restrict__ tab /* per-thread twiddles, [6][256] float4: make_rowq_table() */)
 {
     constexpr int M = RowQ::M;
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__rest
     cf *xbuf = reinterpret_cast<cf *>(smem_raw);
     cf *stg = xbuf + RowQ::XBUF;
     const int t = threadIdx.x, l = t & 63;
-    const int iters = (a.nx + gridDim.x - 1) / gridDim.x;
+    const int iters = LOOP ? (a.nx + gridDim.x - 1) / gridDim.x : 1;
 #ifdef FB_ROW_SAMEROW   /* timing experiment only: every workgroup works on row 0 (no HBM traffic); results are wrong */
     auto row_of = [&](int it, bool &valid) { const int r = it * gridDim.x + blockIdx.x; valid = r < a.nx; return a.x0; };
 #else

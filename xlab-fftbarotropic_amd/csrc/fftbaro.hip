@@ -569,7 +569,10 @@ static int launch_rowq(fb_ctx *c, const RowArgs &a)
     // grid of 1024 looping over rows (the dispatcher's refill keeps the four contexts of a CU out of step; the prologue is cheap)
     int grid = a.nx;
     if (const char *e = getenv("FB_ROW_GRID")) { int v = atoi(e); if (v >= 64 && v < grid) grid = v; }
-    auto kern = c->world > 1 ? k_rowq<true, false> : a.prescaled ? k_rowq<false, true> : k_rowq<false, false>;
+    const bool loop = grid < a.nx;
+    auto kern = c->world > 1 ? (loop ? k_rowq<true, false, true> : k_rowq<true, false, false>)
+              : a.prescaled ? (loop ? k_rowq<false, true, true> : k_rowq<false, true, false>)
+                            : (loop ? k_rowq<false, false, true> : k_rowq<false, false, false>);
     int rc = set_max_lds(c, (const void *)kern, RowQ::LDS_BYTES);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), RowQ::LDS_BYTES, c->stream, a, (const float4 *)c->d_tw_2048);
