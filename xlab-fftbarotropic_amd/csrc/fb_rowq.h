@@ -21,16 +21,15 @@
                       k_col_full -- row pass -1.6 %, k_col_full -1.7 %), 2 = the tendency stores (k_col_full +1 %) */
 #define RQ_NT 1
 #endif
-// Opaque thread id per phase (launder): fewer live registers, but every phase recomputes its LDS addresses.  With one row per workgroup
-// (no row loop to hoist things out of) every instance has the registers to do without: 217 of 381 non-packed vector instructions per row
-// gone, -2.5 % per launch on one GPU.  The looping slab-blocked instance would spill 356 B per lane and keeps it.
-// RQ_LAUNDER_MODE: 3 = always, 0 = never, unset = by instance.
+// Opaque thread id per phase (launder): fewer live registers, but every phase recomputes its LDS addresses.  The one-GPU instances have
+// the registers to do without (118-124 of 128): 217 of 381 non-packed vector instructions per row gone, -2.5 % per launch.  The slab-blocked
+// instances (more address arithmetic) would spill and keep it.  RQ_LAUNDER_MODE: 3 = always, 0 = never, unset = by instance.
 #ifdef RQ_LAUNDER_MODE
 #define RQ_LAUNDER(t) ((RQ_LAUNDER_MODE & 2) ? launder(t) : (t))
 #define RQ_LAUNDER2(t) ((RQ_LAUNDER_MODE & 1) ? launder(t) : (t))
 #else
-#define RQ_LAUNDER(t) ((SLAB && LOOP) ? launder(t) : (t))
-#define RQ_LAUNDER2(t) ((SLAB && LOOP) ? launder(t) : (t))
+#define RQ_LAUNDER(t) (SLAB ? launder(t) : (t))
+#define RQ_LAUNDER2(t) (SLAB ? launder(t) : (t))
 #endif
 struct RowQ {
     static constexpr int M = 2048, N = 4096, T = 256;
@@ -132,7 +131,8 @@ FB_DEV void rq_dma_issue(cf *stg, int t, const RowView &view, int field, int row
     if (t < 2) __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src, nyq, 4, 0, 0);
 }
 
-FB_DEV void rq_ext(cf *v, int t, const cf *stg, cf wx /* exp(+2 pi i t/N) */)
+// wk[e] = exp(+2 pi i (t + 256 e)/N), table values (e = 4: i wk[0], applied as a rotation)
+FB_DEV void rq_ext(cf *v, int t, const cf *stg, const cf *wk)
 {
     constexpr int M = RowQ::M;
 #ifdef FB_R8_NOEXT  /* timing experiment only */
@@ -145,12 +145,8 @@ FB_DEV void rq_ext(cf *v, int t, const cf *stg, cf wx /* exp(+2 pi i t/N) */)
         cf a = lds_rd(&stg[k]), b = lds_rd(&stg[M - k]);
         if (e == 0 && t == 0) { a.y = 0.f; b.y = 0.f; }                               // k = 0: X[0] and X[M] count as real (SURVEY note N2)
         const cf ev = cadd_conj(a, b);
-        cf d = cmul(csub_conj(a, b), wx);
-        switch (e) {                                                                   // e^{2 pi i 256 e/4096} = e^{2 pi i e/16}
-        case 1: d = mul_w16<1, +1>(d); break; case 2: d = mul_w16<2, +1>(d); break; case 3: d = mul_w16<3, +1>(d); break;
-        case 4: d = mul_w16<4, +1>(d); break; case 5: d = mul_w16<5, +1>(d); break; case 6: d = mul_w16<6, +1>(d); break;
-        case 7: d = mul_w16<7, +1>(d); break; default: break;
-        }
+        cf d = cmul(csub_conj(a, b), wk[e == 4 ? 0 : e]);                              // (X[k] - conj X[M-k]) e^{2 pi i k/N}
+        if (e == 4) d = mul_w16<4, +1>(d);
         v[e] = cadd_ib(ev, d);
     }
 }
@@ -180,7 +176,7 @@ __global__ void __launch_bounds__(256) k_rowq_permute_src(const float *__restric
 // the trip count known to be one the compiler no longer hoists the store offsets out of the row loop (which cost a spilled register whose
 // reload sat behind the first store: a wait for that store's acknowledgement in every workgroup).
 template <bool SLAB, bool PRE = false, bool LOOP = false>
-__global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__restrict__ tab /* per-thread twiddles, [6][256] float4: make_rowq_table() */)
+__global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__restrict__ tab /* per-thread twiddles, [9][256] float4: make_rowq_table() */)
 {
     constexpr int M = RowQ::M;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -199,26 +195,30 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__rest
         bool vld; const int x = row_of(0, vld);
         rq_dma_issue<SLAB>(stg, t, a.M, 0, x);
     }
-    // this thread's twiddles, one coalesced table (six 16-byte loads; gathered from the root tables they were twelve loads that
-    // touched up to 28 cache lines per wave instruction):  W_2048^{p t} (p = 1..7), W_256^{q l} (q = 1..3), W_4096^{t}, and for t < 64
-    // the LDS table entry W_64^{p l_lo} at [p = t >> 3][l_lo = t & 7]
+    // this thread's twiddles, one coalesced table (nine 16-byte loads; gathered from the root tables they were twelve loads that
+    // touched up to 28 cache lines per wave instruction):  W_2048^{p t} (p = 1..7), W_256^{q l} (q = 1..3), W_4096^{t}, for t < 64 the LDS
+    // table entry W_64^{p l_lo} at [p = t >> 3][l_lo = t & 7], and W_4096^{t + 256 e} for e = 1, 2, 3, 5, 6, 7 (the even/odd twiddle of every
+    // element as ONE table value: it used to be W_4096^t times a 16th root, two more packed instructions per element and one more rounding)
     RowQTw tw;
-    cf wx;
+    cf wkn[8];                                                                         // exp(+2 pi i (t + 256 e)/4096); wk[4] unused
     cf *tw2 = stg + RowQ::STG;
     {
-        float4 q[6];
+        float4 q[9];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) q[j] = tab[j * 256 + t];
+        for (int j = 0; j < 9; ++j) q[j] = tab[j * 256 + t];
         tw.w0[0] = cf_make(q[0].x, q[0].y); tw.w0[1] = cf_make(q[0].z, q[0].w); tw.w0[2] = cf_make(q[1].x, q[1].y); tw.w0[3] = cf_make(q[1].z, q[1].w);
         tw.w0[4] = cf_make(q[2].x, q[2].y); tw.w0[5] = cf_make(q[2].z, q[2].w); tw.w0[6] = cf_make(q[3].x, q[3].y);
         tw.w1[0] = cf_make(q[3].z, q[3].w); tw.w1[1] = cf_make(q[4].x, q[4].y); tw.w1[2] = cf_make(q[4].z, q[4].w);
-        wx = cf_make(q[5].x, -q[5].y);                                                // exp(+2 pi i t/4096)
+        wkn[0] = cf_make(q[5].x, -q[5].y);
         if (t < 64) tw2[t] = cf_make(q[5].z, q[5].w);
+        wkn[1] = cf_make(q[6].x, -q[6].y); wkn[2] = cf_make(q[6].z, -q[6].w); wkn[3] = cf_make(q[7].x, -q[7].y);
+        wkn[5] = cf_make(q[7].z, -q[7].w); wkn[6] = cf_make(q[8].x, -q[8].y); wkn[7] = cf_make(q[8].z, -q[8].w);
+        wkn[4] = wkn[0];
     }
     tw.w2 = tw2;
 #pragma unroll
     for (int p = 0; p < 7; ++p) asm volatile("" :: "v"(tw.w0[p]));                    // land the table loads here, not behind a later prefetch
-    asm volatile("" :: "v"(tw.w1[0]), "v"(tw.w1[1]), "v"(tw.w1[2]), "v"(wx));
+    asm volatile("" :: "v"(tw.w1[0]), "v"(tw.w1[1]), "v"(tw.w1[2]), "v"(wkn[0]), "v"(wkn[7]));
     RH_WAIT_ROW();
     __syncthreads();
 
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__rest
             const int tp = RQ_LAUNDER(t);
             if (wait) RH_WAIT_ROW();
             lds_barrier();
-            rq_ext(v, tp, stg, wx);
+            rq_ext(v, tp, stg, wkn);
 #ifndef RQ_LATE_DMA   /* -DRQ_LATE_DMA: the next row is sent for behind the exchange barrier instead (one barrier fewer per phase; measured: no gain at ny = 4096 and 16384, 2 % slower in k_rowh2) */
             lds_barrier();
             if (next_row >= 0) rq_dma_issue<SLAB>(stg, tp, a.M, next_field, next_row);
@@ -289,11 +289,7 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__rest
                 const cf wm = lds_rd(&xbuf[M / 2 - k]);
                 const cf ev = cf_make(0.5f * (wk.x + wm.x), 0.5f * (wk.y - wm.y));
                 const cf od = cf_make(0.5f * (wk.y + wm.y), 0.5f * (wm.x - wk.x));
-                cf co = cmulc(od, wx);
-                switch (e) {
-                case 1: co = mul_w16<1, -1>(co); break; case 2: co = mul_w16<2, -1>(co); break; case 3: co = mul_w16<3, -1>(co); break;
-                default: break;
-                }
+                const cf co = cmulc(od, wkn[e]);                       // e^{-2 pi i k/N} O
                 if (row_keep<SLAB>(a.T, a.t_frozen, k)) st2<(RQ_NT & 2) != 0>(const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x, k)), cadd(ev, co));
                 const cf tm = csub(ev, co);
                 if (row_keep<SLAB>(a.T, a.t_frozen, M - k)) st2<(RQ_NT & 2) != 0>(const_cast<cf *>(row_ptr<SLAB>(a.T, 0, x, M - k)), cf_make(tm.x, -tm.y));

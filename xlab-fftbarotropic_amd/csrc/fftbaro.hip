@@ -140,19 +140,21 @@ static std::vector<cf> make_root_table(int n)
     return t;
 }
 
-// k_rowq's per-thread twiddles, [6][256] float4 = twelve complex per thread t (fb_rowq.h): W_2048^{p t} (p = 1..7), W_256^{q (t & 63)}
-// (q = 1..3), W_4096^{t}, and for t < 64 W_64^{(t >> 3)(t & 7)}; the very values of the root tables
+// k_rowq's per-thread twiddles, [9][256] float4 = eighteen complex per thread t (fb_rowq.h): W_2048^{p t} (p = 1..7), W_256^{q (t & 63)}
+// (q = 1..3), W_4096^{t}, for t < 64 W_64^{(t >> 3)(t & 7)}, and W_4096^{t + 256 e} for e = 1, 2, 3, 5, 6, 7; the very values of the root tables
 static std::vector<cf> make_rowq_table()
 {
     const std::vector<cf> r2048 = make_root_table(2048), r4096 = make_root_table(4096);
-    std::vector<cf> tab(12 * 256);
+    std::vector<cf> tab(18 * 256);
     for (int t = 0; t < 256; ++t) {
-        cf e[12];
+        cf e[18];
         for (int p = 1; p < 8; ++p) e[p - 1] = r2048[(p * t) % 2048];
         for (int q = 1; q < 4; ++q) e[6 + q] = r2048[(8 * q * (t & 63)) % 2048];
         e[10] = r4096[t];
         e[11] = t < 64 ? r2048[(32 * (t & 7) * (t >> 3)) % 2048] : cf{0.f, 0.f};
-        for (int j = 0; j < 6; ++j) { tab[(j * 256 + t) * 2] = e[2 * j]; tab[(j * 256 + t) * 2 + 1] = e[2 * j + 1]; }
+        const int es[6] = {1, 2, 3, 5, 6, 7};
+        for (int i = 0; i < 6; ++i) e[12 + i] = r4096[t + 256 * es[i]];
+        for (int j = 0; j < 9; ++j) { tab[(j * 256 + t) * 2] = e[2 * j]; tab[(j * 256 + t) * 2 + 1] = e[2 * j + 1]; }
     }
     return tab;
 }
