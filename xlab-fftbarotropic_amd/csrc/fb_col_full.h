@@ -85,7 +85,9 @@ FB_DEV void cf_xchg_lanes(cf *lds, cf *v, int w, int l, int c)
     cf *reg = lds + w * (16 * CF_X2_STR);
 #pragma unroll
     for (int r = 0; r < 16; ++r) lds_wr(&reg[r * CF_X2_STR + l * 4 + c], v[r]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-local: DS ops of a wave are in order
+#ifdef CF_LANES_WAIT     /* not needed: the DS operations of a wave execute in order, the reads below see these writes (as in r8_xch_wave) */
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = lds_rd(&reg[l * CF_X2_STR + r * 4 + c]);
