@@ -21,6 +21,13 @@
 #pragma once
 #include "fb_row8.h"
 
+// Opaque thread id per phase (launder, see fb_rowq.h): needed where the registers are short (V = 1: 122 of 128); at V = 2 the kernel runs two
+// waves per SIMD with up to 256 registers and the one-GPU instance can keep its LDS addresses (246, no scratch; the slab-blocked one would spill
+// 600 B).  RH_LAUNDER_ALL=1: always.
+#ifndef RH_LAUNDER_ALL
+#define RH_LAUNDER_ALL 0
+#endif
+#define RH_LAUNDER(t) ((V == 1 || SLAB || RH_LAUNDER_ALL) ? launder(t) : (t))
 #ifndef RH_NT      /* nontemporal hint on the LDS-DMA loads of the four fields (as RQ_NT in fb_rowq.h) */
 #define RH_NT 0
 #endif
@@ -238,7 +245,7 @@ __global__ void __launch_bounds__(512, RowH<V>::MIN_WAVES) k_rowh(RowArgs a, con
         // one backward transform: wait for its row, pre-process it out of the staging area, send for the next row, transform.
         // Per-phase opaque thread id: otherwise the staging and exchange addresses of all four phases stay live in registers.
         auto c2r_phase = [&](bool wait, int next_field, int next_row) {
-            const int tp = launder(t);
+            const int tp = RH_LAUNDER(t);
             if (wait) RH_WAIT_ROW();                                  // (the first phase's row was waited for before the previous stores)
             lds_barrier();
             rh_ext<V>(v, tp, stg, wx);
@@ -276,7 +283,7 @@ __global__ void __launch_bounds__(512, RowH<V>::MIN_WAVES) k_rowh(RowArgs a, con
                 for (int e = 0; e < 8; ++e)                           // - u*dvortdx - v*dvortdy          main.cpp:214,225-227
                     v[s][e] = cf_make(p[s][e].x - (v[s][e].x * a.scale) * zy[s][e].x, p[s][e].y - (v[s][e].y * a.scale) * zy[s][e].y);
         }
-        const int tt = launder(t), wl = tt >> 6, ll = tt & 63;
+        const int tt = RH_LAUNDER(t), wl = tt >> 6, ll = tt & 63;
         if (a.src) {                                                  // ... + vort_src (permuted order); the loads and their wait stay in this branch
             const float2 *sp = reinterpret_cast<const float2 *>(a.src) + (size_t)x * M + tt;
 #pragma unroll
