@@ -68,12 +68,28 @@ def pmc_traffic(prof, kernel, launches_per_step=4):
                 continue
             if kernel == "k_col_full" and k.startswith("k_col_full<4"):       # the PRIME launch after set_vort is not a stage
                 continue
+            if kernel == "k_col_strided_bwd4":
+                # per[kernel] is the duration of the four-field launch of an RK stage; the same kernel also runs single-field
+                # launches in set_vort / get_vort: only the large launches count (tools/pmc_summary.py)
+                if "hbm_bytes_per_big_launch_corrected" not in d:
+                    return None                                               # an older summary that mixed both: no figure rather than a wrong one
+                tot += d["hbm_bytes_per_big_launch_corrected"] * d["launches_big"]
+                cnt += d["launches_big"]
+                continue
             tot += d["hbm_bytes_per_launch_corrected"] * d["launches"]
             cnt += d["launches"]
     return tot / cnt if cnt else None
 
 
-def cpu_leg(n, dt, kind, steps, threads):
+def oracle_source(O, n):
+    """The FIFO producer's cake (vort_src_input.cpp:35-46) as the oracle builds it."""
+    import numpy as np
+    src = np.zeros((n, n), dtype=np.float32)
+    O.add_cake(src, 600000.0, 600000.0, 600000.0 / 2 + 50000.0, 600000.0 / 2, 3e-3 / 10800.0, 30000.0)
+    return src
+
+
+def cpu_leg(n, dt, kind, steps, threads, source=False):
     import ctypes
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
@@ -83,13 +99,15 @@ def cpu_leg(n, dt, kind, steps, threads):
         threads = 1
     m = O.Model(n, n, dt=dt)
     m.set_vort(O.make_field(kind, n))
+    if source:
+        m.set_source(oracle_source(O, n))
     m.step(1)
     t0 = time.perf_counter()
     m.step(steps)
     return steps / (time.perf_counter() - t0), threads
 
 
-def cpu_baseline(n, dt, kind, steps):
+def cpu_baseline(n, dt, kind, steps, source=False):
     """The oracle ("port": the reference's unfused loop structure with its own FFT) on the GPU box's host cores: ONE core is
     the faithful figure -- the reference is single-threaded (Makefile:2, no threads anywhere) -- plus the same code on all
     cores (OpenMP) and the small configs, as SURVEY.md 8(d) asks.  Bounded: about 20-30 s in all."""
@@ -103,16 +121,16 @@ def cpu_baseline(n, dt, kind, steps):
         pass
     if share == nproc and nproc > 16:
         share, how = 16, "the GPU box's CPU share for one GPU (16), nproc reports the whole host"
-    v1, _ = cpu_leg(n, dt, kind, steps, 1)
-    vall, used = cpu_leg(n, dt, kind, max(steps, 5), share)
+    v1, _ = cpu_leg(n, dt, kind, steps, 1, source)
+    vall, used = cpu_leg(n, dt, kind, max(steps, 5), share, source)
     small = {}
     for ns, ks in ((256, 40), (1024, 20)):
         if ns < n:
             v, _ = cpu_leg(ns, 3.0, "elliptic", ks, 1)
             small["%dx%d elliptic, 1 core" % (ns, ns)] = v
     return {"value": v1, "unit": "steps/s", "cores": 1, "kind": "port",
-            "sample": "%dx%d %s, %d RK4 steps after 1 warm-up, oracle/liboracle.so (own FFT, reference loop structure), 1 thread"
-                      % (n, n, kind, steps),
+            "sample": "%dx%d %s%s, %d RK4 steps after 1 warm-up, oracle/liboracle.so (own FFT, reference loop structure), 1 thread"
+                      % (n, n, kind, " + source" if source else "", steps),
             "all_cores": {"value": vall, "unit": "steps/s", "cores": used, "nproc": nproc,
                           "sample": "same workload, %d steps, OpenMP over the oracle's loops and FFT batches; threads = %s" % (max(steps, 5), how)},
             "other_configs_steps_per_s": small}
@@ -124,7 +142,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--grid", "--n", dest="n", type=int, default=4096, help="grid points per side")
-    ap.add_argument("--kind", default=None, help="initial field (default: kuo2004 for n>=4096 else elliptic)")
+    ap.add_argument("--kind", default=None, help="initial field (default: the BASELINE config of the grid: 4096 kuo2004, 8192 gaussian, "
+                                                  "16384 kuo2004 + source; smaller grids elliptic)")
+    ap.add_argument("--source", type=int, default=None, help="1: the source-forced variant (main-shallow-water.cpp:277-338) with the FIFO "
+                                                             "producer's cake switched on; default: on for --grid 16384 (BASELINE configs[4])")
     ap.add_argument("--cpu-steps", type=int, default=5, help="oracle steps for the 1-core cpu_baseline leg (0 = skip cpu_baseline)")
     ap.add_argument("--spinup-steps", type=int, default=None,
                     help="untimed device spin-up before the warm-up: this many steps, then the state is reset (default: ~30 ms worth; 0 = none)")
@@ -143,7 +164,8 @@ def main():
 
     import xlab_fftbarotropic_amd as X
     n = args.n
-    kind = args.kind or ("kuo2004" if n >= 4096 else "elliptic")
+    kind = args.kind or ("gaussian" if n == 8192 else ("kuo2004" if n >= 4096 else "elliptic"))      # BASELINE configs 2-5
+    with_source = bool(args.source) if args.source is not None else n == 16384                         # configs[4]: main-shallow-water.cpp path
     dt = 3.0 if n <= 1024 else 3.0 * 1024 / n
     K, W = args.steps, args.warmup
     slab_info = None
@@ -161,7 +183,11 @@ def main():
         slab_info = {"rows_per_rank": model.XL, "active_cols_per_rank": model.KA, "frozen_cols_per_rank": model.KF,
                      "field_groups": model.field_groups, "row_chunks": model.row_chunks,
                      "transport": model.transport}
+        if args.backend == "nccl" and not model.transport.startswith("rccl (engine"):
+            raise SystemExit("bench.py: the multi-GPU line is only printed for the engine's RCCL transport, got %r" % model.transport)
         v0_local = torch.from_numpy(slab.local_rows(X.make_field(kind, n), rank, world)).cuda()
+        if with_source:
+            model.set_source_local(torch.from_numpy(slab.local_rows(X.make_source_kuo2004(n), rank, world)).cuda())
 
         def reset_state():
             model.set_vort_local(v0_local)
@@ -170,6 +196,8 @@ def main():
     else:
         model = X.Model(n, n, dt=dt)
         v0 = torch.from_numpy(X.make_field(kind, n)).cuda()      # device copy: resetting the state does not idle the GPU
+        if with_source:                                          # vort_src as the FIFO producer hands it over (vort_src_input.cpp:35-46), in force for every step
+            model.set_source(X.make_source_kuo2004(n))
 
         def reset_state():
             model.set_vort(v0)
@@ -209,6 +237,8 @@ def main():
         # how much of that is local work: the same schedule with a transport that moves nothing (fields are garbage, timing is not)
         m0 = slab.EngineSlab(n, n, dt=dt, rank=rank, world=world, transport="null", dist=dist)
         m0.set_vort_local(v0_local)
+        if with_source:
+            m0.set_source_local(torch.from_numpy(slab.local_rows(X.make_source_kuo2004(n), rank, world)).cuda())
         m0.step(max(1, min(W, 3)))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -226,8 +256,10 @@ def main():
         "metric": "RK4 steps/sec, %dx%d periodic grid" % (n, n), "value": steps_per_s, "unit": "steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "spinup_steps": args.spinup_steps,
-        "config": {"workload": "%dx%d %s initial field, nu=6.5, L=600 km, dt=%.4g s, 4 RK stages/step, fused HIP path"
-                               % (n, n, kind, dt), "grid": [n, n], "parallelism": "slab%d" % world if world > 1 else "single"},
+        "config": {"workload": "%dx%d %s initial field%s, nu=6.5, L=600 km, dt=%.4g s, 4 RK stages/step, fused HIP path"
+                               % (n, n, kind, ", source-forced (main-shallow-water.cpp path: vort_src = the FIFO producer's cake, in force every step)"
+                                  if with_source else "", dt),
+                   "grid": [n, n], "source": with_source, "parallelism": "slab%d" % world if world > 1 else "single"},
         "achieved_hbm_GBs": alg_bytes * steps_per_s / 1e9,
         "step_roofline_frac": alg_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBS * world),
         "tight_frac": 256.0 * n * n * steps_per_s / 1e9 / (HBM_PEAK_GBS * world),
@@ -265,7 +297,7 @@ def main():
             out["traffic_bytes_per_step"] = per_step
             out["traffic_frac"] = per_step * steps_per_s / 1e9 / HBM_PEAK_GBS
         if args.cpu_steps > 0:
-            out["cpu_baseline"] = cpu_baseline(n, dt, kind, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(n, dt, kind, args.cpu_steps, with_source)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -84,6 +84,9 @@ int fb_event_record(void *event, void *stream);
 int fb_stream_wait_event(void *stream, void *event);
 int fb_event_synchronize(void *event);
 int fb_memcpy_d2h_async(void *stream, void *h_dst, const void *d_src, size_t bytes);
+/* the other direction, for the FIFO source (main-shallow-water.cpp:304: a reader thread fills a pinned buffer, the copy
+ * stream carries it to the device, the compute stream waits for the copy's event before fb_model_set_source) */
+int fb_memcpy_h2d_async(void *stream, void *d_dst, const void *h_src, size_t bytes);
 
 /* ---------------------------------------------------------------------------------------
  * Spectral operators on device half spectra (nx*(ny/2+1) complex).  in == out is allowed
@@ -201,6 +204,10 @@ int fb_slab_get_vort_local(fb_slab *s, float *d_rows);
 int fb_slab_get_diag_local(fb_slab *s, float *d_psi, float *d_u, float *d_v);
 int fb_slab_step(fb_slab *s, int nsteps);
 int fb_slab_synchronize(fb_slab *s);
+/* the rank's compute stream is the engine's own: record an event behind what has been queued on it (fb_slab_get_*_local ->
+ * copy stream) or make it wait for one (H2D of a new source -> fb_slab_set_source_local); events from fb_event_create */
+int fb_slab_record_event(fb_slab *s, void *event);
+int fb_slab_wait_event(fb_slab *s, void *event);
 int fb_slab_time_steps(fb_slab *s, int nsteps, float *total_ms);
 /* exchanges a known pattern of world*count floats through the connected transport; *wrong_words = 0 when every word arrived */
 int fb_slab_transport_selftest(fb_slab *s, size_t count, size_t *wrong_words);

@@ -12,7 +12,15 @@ Run in the build container only (the GPU box never regenerates them):
       configs[1] -- 1024^2 elliptic vortex, dt = 3 s -- sub-sampled (every 4th point) after 1000 steps: the
       oracle's own 1000-step cross-check.
 
-Neither is a reference output: the reference's FFT-dependent programs cannot be built here (no FFTW) and the
+  oracle_8192_step300.npz   : the oracle on BASELINE configs[3] -- 8192^2 gaussian vortex (makefield-gaussian.cpp:14-31),
+      dt = 0.375 s -- vort[::32, ::32] after 10, 100 and 300 steps, full-field L2 norms and sums (~1 h on 5 cores, 5 GiB).
+  oracle_16384_src_step12.npz : the oracle on BASELINE configs[4] -- 16384^2 Kuo2004 initial field, the source-forced loop
+      of main-shallow-water.cpp:277-338 with the FIFO producer's schedule (vort_src_input.cpp:35-61) shifted so that it is
+      active: the cake 3e-3/duration at (L/2 + 50 km, L/2), R = 30 km arrives with flag 1 before step 2 and the zeroed field
+      before step 6; dt = 0.1875 s -- vort[::64, ::64] after 1, 5, 8 and 12 steps, L2 norms and sums (~15 min on 8 cores,
+      ~19 GiB).
+
+None of them is a reference output: the reference's FFT-dependent programs cannot be built here (no FFTW) and the
 reference holds no fixtures ("parity unpinned" by the reference).
 """
 import os
@@ -49,6 +57,59 @@ def oracle4096():
     print("done in %.0f s" % (time.time() - t0))
 
 
+def _snap(out, tag, v, sub):
+    v64 = v.astype(np.float64)
+    out["vort_sub%d_step%s" % (sub, tag)] = v[::sub, ::sub].copy()
+    out["l2_step%s" % tag] = np.float64(np.sqrt((v64 * v64).sum()))
+    out["sum_step%s" % tag] = np.float64(v64.sum())
+
+
+def oracle8192():
+    import oracle_py as O
+    n, dt, sub = 8192, 0.375, 32
+    m = O.Model(n, n, dt=dt)
+    m.set_vort(O.make_field("gaussian", n))
+    out = {"note": np.array("oracle/liboracle.so, 8192^2 gaussian (makefield-gaussian.cpp:14-31), nu=6.5, L=600 km, dt=0.375 s; "
+                            "vort[::32, ::32], full-field l2 = sqrt(sum(vort^2)) in float64; made by "
+                            "tests/golden/make_long_fixtures.py oracle8192")}
+    done, t0 = 0, time.time()
+    for upto in (10, 100, 300):
+        while done < upto:
+            m.step(10)
+            done += 10
+            print("step %d  %.0f s" % (done, time.time() - t0), flush=True)
+        _snap(out, str(upto), m.vort(), sub)
+        np.savez_compressed(os.path.join(HERE, "oracle_8192_step300.npz"), **out)
+    print("done in %.0f s" % (time.time() - t0))
+
+
+def oracle16384():
+    import oracle_py as O
+    n, dt, sub, L = 16384, 0.1875, 64, 600000.0
+    on_step, off_step = 2, 6                       # the producer's beg_step / end_step (vort_src_input.cpp:40-41), shifted
+    m = O.Model(n, n, dt=dt)
+    m.set_vort(O.make_field("kuo2004", n))
+    out = {"note": np.array("oracle/liboracle.so, 16384^2 kuo2004 + source (main-shallow-water.cpp:277-338): cake 3e-3/10800 at "
+                            "(L/2+50 km, L/2), R=30 km handed over before step 2, zeros before step 6; nu=6.5, L=600 km, "
+                            "dt=0.1875 s; vort[::64, ::64]; made by tests/golden/make_long_fixtures.py oracle16384"),
+           "on_step": np.int64(on_step), "off_step": np.int64(off_step)}
+    t0 = time.time()
+    for step in range(1, 13):
+        if step == on_step:
+            src = np.zeros((n, n), dtype=np.float32)
+            O.add_cake(src, L, L, L / 2 + 50000.0, L / 2, 3e-3 / 10800.0, 30000.0)      # vort_src_input.cpp:46
+            m.set_source(src)
+            del src
+        elif step == off_step:
+            m.set_source(np.zeros((n, n), dtype=np.float32))                              # vort_src_input.cpp:52-55
+        m.step(1)
+        print("step %d  %.0f s" % (step, time.time() - t0), flush=True)
+        if step in (1, 5, 8, 12):
+            _snap(out, str(step), m.vort(), sub)
+            np.savez_compressed(os.path.join(HERE, "oracle_16384_src_step12.npz"), **out)
+    print("done in %.0f s" % (time.time() - t0))
+
+
 def fp64_1024():
     import oracle_py as O
     import ref_numpy as R
@@ -69,4 +130,4 @@ def fp64_1024():
 
 
 if __name__ == "__main__":
-    {"oracle4096": oracle4096, "fp64_1024": fp64_1024}[sys.argv[1]]()
+    {"oracle4096": oracle4096, "fp64_1024": fp64_1024, "oracle8192": oracle8192, "oracle16384": oracle16384}[sys.argv[1]]()

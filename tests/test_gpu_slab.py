@@ -327,11 +327,12 @@ def test_engine_slab_two_processes_gloo_matches_single(tmp_path):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-def test_engine_slab_rccl_on_several_gpus(tmp_path):
+@pytest.mark.parametrize("env", [{}, {"FB_SLAB_FIELD_GROUPS": "4", "FB_SLAB_ROW_CHUNKS": "2"}])
+def test_engine_slab_rccl_on_several_gpus(tmp_path, env):
     """The product transport on real hardware: one process per GPU, ncclCommInitRank + grouped ncclSend/ncclRecv over xGMI, against
     the single-GPU run of the same kernels (bit for bit).  Needs at least two GPUs in one box -- skipped on the one-GPU boxes the
     builder has (there the RCCL call path is covered with world = 1 by test_transport_selftests and the schedule by the
-    threads-as-ranks tests above)."""
+    threads-as-ranks tests above).  Second case: the two-stream pipelined plan (field groups and row chunks forced)."""
     import subprocess
     import sys
     import torch
@@ -356,7 +357,7 @@ def test_engine_slab_rccl_on_several_gpus(tmp_path):
         "m.close(); dist.destroy_process_group()\n" % (ROOT, str(tmp_path)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=dict(os.environ, **env))
     assert res.returncode == 0, res.stderr[-3000:]
     import xlab_fftbarotropic_amd as X
     n = 1024
@@ -366,3 +367,57 @@ def test_engine_slab_rccl_on_several_gpus(tmp_path):
     ref.step(5)
     got = np.concatenate([np.load(str(tmp_path / ("rows%d.npy" % r))) for r in range(world)], axis=0)
     assert np.array_equal(got.view(np.uint32), ref.vort().cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("env", [{}, {"FB_SLAB_FIELD_GROUPS": "4", "FB_SLAB_ROW_CHUNKS": "2"}])
+def test_cpp_driver_one_process_per_gpu_rccl(tmp_path, env):
+    """host/barotropic_main.out --world P --rank r --comm-file F --launch-token T: the C++ multi-process flow over RCCL
+    (rank 0 publishes the ncclUniqueId through the comm file, a stale record of another launch lies at the path and must be
+    ignored), once with the default plan and once with the two-stream pipelined one, against the single-GPU run of
+    the same configuration.  Needs >= 2 GPUs in one box."""
+    import subprocess
+    import torch
+    import oracle_py as O
+    ngpu = torch.cuda.device_count()
+    if ngpu < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    world = 4 if ngpu >= 4 else 2
+    host = os.path.join(ROOT, "xlab-fftbarotropic_amd", "host")
+    subprocess.check_call(["make", "-s", "-C", host])
+    exe = os.path.join(host, "barotropic_main.out")
+    n, steps = 1024, 21
+    outs = {}
+    for tag in ("one", "many"):
+        d = tmp_path / tag
+        (d / "input").mkdir(parents=True)
+        (d / "output").mkdir()
+        O.make_field("elliptic", n).tofile(str(d / "input" / "initial_vorticity.bin"))
+        base = [exe, "--npts", str(n), "--steps", str(steps), "--record-step", "10"]
+        if tag == "one":
+            res = [subprocess.run(base, cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)]
+        else:
+            comm = str(d / "comm")
+            subprocess.check_call([os.path.join(host, "comm_bootstrap_check.out"), "publish", comm, "an-older-launch", "7"])
+            procs = [subprocess.Popen(base + ["--world", str(world), "--rank", str(r), "--comm-file", comm, "--launch-token", "t-%d" % os.getpid(),
+                                              "--comm-timeout", "120"], cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                      env=dict(os.environ, **env)) for r in range(world)]
+            res = []
+            for p in procs:
+                try:
+                    so, se = p.communicate(timeout=600)
+                except subprocess.TimeoutExpired:
+                    for q in procs:
+                        q.kill()
+                    raise
+                res.append(subprocess.CompletedProcess(p.args, p.returncode, so, se))
+        for r in res:
+            assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = res[0].stdout
+    assert outs["one"] == outs["many"]                                        # rank 0 owns the banner and the step lines
+    rd = lambda tag, f: np.fromfile(str(tmp_path / tag / "output" / f), dtype="<f4")
+    import ref_numpy as R
+    for step in (0, 10, 20):
+        a, b = rd("one", "vort_step_%d.bin" % step), rd("many", "vort_step_%d.bin" % step)
+        assert a.size == n * n and R.rel_l2(b, a) < 2e-6, step                 # single-pass x transform on one GPU, three kernels on the ranks
+        for name in ("psi", "u", "v"):
+            assert R.rel_l2(rd("many", "%s_step_%d.bin" % (name, step)), rd("one", "%s_step_%d.bin" % (name, step))) < 2e-6

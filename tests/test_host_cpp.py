@@ -21,7 +21,8 @@ def test_host_programs_link():
     import xlab_fftbarotropic_amd as X
     X.build_lib()
     _build()
-    for exe in ("barotropic_main.out", "shim_check.out", "invert_pres.out", "vort_src_input.out", "find_min.out", "fftw_shape_check.out"):
+    for exe in ("barotropic_main.out", "shim_check.out", "invert_pres.out", "vort_src_input.out", "find_min.out", "fftw_shape_check.out",
+                "comm_bootstrap_check.out"):
         assert os.access(os.path.join(HOST, exe), os.X_OK)
 
 
@@ -471,3 +472,37 @@ def test_driver_four_ranks_as_threads_match_the_single_gpu_run(tmp_path):
         for name in ("psi", "u", "v"):
             assert R.rel_l2(rd("four", "%s_step_%d.bin" % (name, step)), rd("one", "%s_step_%d.bin" % (name, step))) < 1e-6, (name, step)
     assert rd("one", "vort_src_input_step_100.bin").max() > 0 and rd("one", "vort_src_input_step_200.bin").max() == 0
+
+
+def test_comm_file_bootstrap_never_takes_a_stale_id(tmp_path):
+    """host/comm_bootstrap.hpp (the --comm-file hand-over of barotropic_main.out --world P --rank r; VERDICT r2 / ADVICE r2):
+    a leftover record of a previous launch must not reach ncclCommInitRank.  No GPU: comm_bootstrap_check.out is the header's
+    command-line face."""
+    import time
+    _build()
+    exe = os.path.join(HOST, "comm_bootstrap_check.out")
+    f = str(tmp_path / "comm")
+    run = lambda *a, **k: subprocess.run([exe] + [str(x) for x in a], stdout=subprocess.PIPE, text=True, timeout=60, **k)
+    # 1. tokens: a stale record of launch A lies there; the reader of launch B waits for B's record
+    assert run("publish", f, "launch-A", 17).returncode == 0
+    rd = subprocess.Popen([exe, "await", f, "launch-B", "20"], stdout=subprocess.PIPE, text=True)
+    time.sleep(0.5)
+    assert rd.poll() is None                                            # still waiting: A's record was not taken
+    assert run("publish", f, "launch-B", 42).returncode == 0
+    assert rd.communicate(timeout=30)[0].strip() == "id 42" and rd.returncode == 0
+    # 2. rank 0 removes whatever lies at the path before anything else
+    assert run("prepare", f).returncode == 0 and not os.path.exists(f)
+    r = run("await", f, "launch-B", "1")
+    assert r.stdout.strip() == "timeout" and r.returncode == 3
+    # 3. no token: only a fresh record counts (older than max-age at the reader's start -> skipped), a fresh one is taken
+    assert run("publish", f, "", 5).returncode == 0
+    old = time.time() - 1000
+    os.utime(f, (old, old))
+    assert run("await", f, "", "1", "60").stdout.strip() == "timeout"
+    assert run("publish", f, "", 6).returncode == 0
+    assert run("await", f, "", "5", "60").stdout.strip() == "id 6"
+    # 4. a foreign or truncated file is not a record
+    open(f, "wb").write(b"\0" * 128)                                    # round 2's format: a bare id
+    assert run("await", f, "", "1").stdout.strip() == "timeout"
+    # 5. an over-long token is refused
+    assert run("publish", f, "x" * 64, 1).returncode == 1

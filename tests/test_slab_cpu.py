@@ -121,3 +121,67 @@ def test_slab_geometry_plan_and_world1():
     ref.set_vort(v0)
     ref.step(2)
     assert R.rel_l2(m.vort_local().numpy(), ref.vort()) < 1e-10
+
+
+def _connect_worker(rank, world, port, fail_rank, fail_step, out_path):
+    """EngineSlab._connect_rccl over gloo with a stand-in for the engine library: `fail_step` ("id" on rank 0, "init" on
+    `fail_rank`) reports an error; what is under test is that EVERY rank then raises, after the same collectives."""
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from importlib import import_module
+    slab = import_module("xlab-fftbarotropic_amd.slab")
+    B = import_module("xlab-fftbarotropic_amd.binding")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        seen = {}
+
+        class FakeLib:
+            def fb_slab_unique_id(self, buf):
+                if fail_step == "id":
+                    return 1
+                buf.raw = bytes(range(128))
+                return 0
+
+            def fb_slab_connect_rccl(self, h, buf):
+                seen["id"] = bytes(buf.raw[:128])
+                return 1 if (fail_step == "init" and rank == fail_rank) else 0
+
+        class FakeB:
+            FftBaroError = B.FftBaroError
+
+            @staticmethod
+            def check(status):
+                if status != 0:
+                    raise B.FftBaroError("stand-in failure")
+
+        class Fake:
+            pass
+        f = Fake()
+        f.torch, f.dist, f.B, f.L, f.rank, f.world, f._h = torch, dist, FakeB, FakeLib(), rank, world, None
+        f._agree = lambda ok, what: slab.EngineSlab._agree(f, ok, what)
+        try:
+            slab.EngineSlab._connect_rccl(f)
+            outcome = "connected"
+        except B.FftBaroError as e:
+            outcome = "raised: %s" % e
+        dist.barrier()                                             # the ranks are still in step: nobody is stuck in a stray collective
+        ok_id = seen.get("id") == bytes(range(128)) if fail_step != "id" else "id" not in seen
+        open(out_path % rank, "w").write("%s|%s" % (outcome, ok_id))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank,fail_step", [(None, None), (0, "id"), (1, "init"), (0, "init")])
+def test_rccl_connect_outcome_is_collective(tmp_path, fail_rank, fail_step):
+    """a failed RCCL bootstrap must fail on ALL ranks -- no rank may fall back on its own."""
+    world, port = 2, _free_port()
+    out = str(tmp_path / "outcome_%d.txt")
+    mp.spawn(_connect_worker, args=(world, port, fail_rank, fail_step, out), nprocs=world, join=True)
+    got = [open(out % r).read().split("|") for r in range(world)]
+    for r in range(world):
+        assert got[r][1] == "True", got
+        if fail_step is None:
+            assert got[r][0] == "connected", got
+        else:
+            assert got[r][0].startswith("raised"), got

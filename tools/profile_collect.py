@@ -24,5 +24,8 @@ for k, v in pmc.items():
     b = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
     out["kernels"][k] = {"FETCH_SIZE_KB_avg": v["FETCH_SIZE"], "WRITE_SIZE_KB_avg": v["WRITE_SIZE"], "launches": v["launches"],
                          "hbm_bytes_per_launch_corrected": b, "in_units_of_C": round(b / C, 2)}
+    if "FETCH_SIZE_big" in v and "WRITE_SIZE_big" in v:        # the kernel's large launches only (four-field k_col_strided<N1, 1>)
+        bb = (2 * v["FETCH_SIZE_big"] + v["WRITE_SIZE_big"]) * 1024
+        out["kernels"][k].update({"hbm_bytes_per_big_launch_corrected": bb, "big_in_units_of_C": round(bb / C, 2), "launches_big": v["launches_big"]})
 json.dump(out, open(os.path.join(dst, "%s_pmc_traffic_%d.json" % (tag, n)), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v["in_units_of_C"] for k, v in out["kernels"].items()}, indent=1))

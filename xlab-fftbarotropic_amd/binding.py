@@ -124,7 +124,7 @@ EXPORTS = [
     "fb_local_hub_destroy", "fb_slab_connect_local", "fb_slab_connect_callback", "fb_slab_set_vort_local", "fb_slab_set_source_local",
     "fb_slab_get_vort_local", "fb_slab_get_diag_local", "fb_slab_step", "fb_slab_synchronize", "fb_slab_time_steps", "fb_slab_transport_selftest", "fb_slab_info", "fb_slab_geometry", "fb_slab_plan",
     "fb_malloc_host", "fb_free_host", "fb_stream_create", "fb_stream_destroy", "fb_stream_synchronize", "fb_event_create",
-    "fb_event_destroy", "fb_event_record", "fb_stream_wait_event", "fb_event_synchronize", "fb_memcpy_d2h_async",
+    "fb_event_destroy", "fb_event_record", "fb_stream_wait_event", "fb_event_synchronize", "fb_memcpy_d2h_async", "fb_memcpy_h2d_async", "fb_slab_record_event", "fb_slab_wait_event",
 ]
 
 

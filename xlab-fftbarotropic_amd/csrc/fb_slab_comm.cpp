@@ -75,14 +75,21 @@ struct RcclTransport { ncclComm_t comm; int rank, world; bool self_through_rccl;
 int rccl_alltoall(void *self, const float *send, float *recv, size_t stride, size_t offset, size_t count, hipStream_t stream)
 {
     RcclTransport *t = (RcclTransport *)self;
-    // one group = one fused launch: every peer's block leaves over its own xGMI link at the same time
+    // one group = one fused launch: every peer's block leaves over its own xGMI link at the same time.  The group is always
+    // closed, also when a send or receive was refused: an open group would swallow every later RCCL call of this thread.
     NCCLCHK(g_rccl.GroupStart());
-    for (int p = 0; p < t->world; ++p) {
+    ncclResult_t bad = ncclSuccess;
+    const char *what = "";
+    for (int p = 0; p < t->world && bad == ncclSuccess; ++p) {
         if (p == t->rank && !t->self_through_rccl) continue;
-        NCCLCHK(g_rccl.Send(send + (size_t)p * stride + offset, count, ncclFloat, p, t->comm, stream));
-        NCCLCHK(g_rccl.Recv(recv + (size_t)p * stride + offset, count, ncclFloat, p, t->comm, stream));
+        bad = g_rccl.Send(send + (size_t)p * stride + offset, count, ncclFloat, p, t->comm, stream);
+        if (bad != ncclSuccess) { what = "ncclSend"; break; }
+        bad = g_rccl.Recv(recv + (size_t)p * stride + offset, count, ncclFloat, p, t->comm, stream);
+        if (bad != ncclSuccess) what = "ncclRecv";
     }
-    NCCLCHK(g_rccl.GroupEnd());
+    const ncclResult_t end = g_rccl.GroupEnd();
+    if (bad != ncclSuccess) return fail(FB_EHIP, std::string(what) + ": " + g_rccl.GetErrorString(bad));
+    if (end != ncclSuccess) return fail(FB_EHIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(end));
     if (!t->self_through_rccl)                             // this rank's own block never touches a link
         HIPCHK(hipMemcpyAsync(recv + (size_t)t->rank * stride + offset, send + (size_t)t->rank * stride + offset, count * sizeof(float),
                               hipMemcpyDeviceToDevice, stream));

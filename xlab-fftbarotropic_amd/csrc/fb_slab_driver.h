@@ -384,6 +384,20 @@ extern "C" int fb_slab_synchronize(fb_slab *s)
     return FB_OK;
 }
 
+// hand-overs between the rank's compute stream and a host-side copy stream (record path and source staging of the driver)
+extern "C" int fb_slab_record_event(fb_slab *s, void *event)
+{
+    if (!s || !event) return fail(FB_EINVAL, "fb_slab_record_event: NULL");
+    HIPCHK(hipEventRecord((hipEvent_t)event, s->comp));
+    return FB_OK;
+}
+extern "C" int fb_slab_wait_event(fb_slab *s, void *event)
+{
+    if (!s || !event) return fail(FB_EINVAL, "fb_slab_wait_event: NULL");
+    HIPCHK(hipStreamWaitEvent(s->comp, (hipEvent_t)event, 0));
+    return FB_OK;
+}
+
 // wall time of `nsteps` steps on this rank's compute stream (HIP events); the caller takes the maximum over ranks
 extern "C" int fb_slab_time_steps(fb_slab *s, int nsteps, float *total_ms)
 {

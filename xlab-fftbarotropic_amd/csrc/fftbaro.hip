@@ -420,6 +420,12 @@ extern "C" int fb_memcpy_d2h_async(void *stream, void *h_dst, const void *d_src,
     HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return FB_OK;
 }
+extern "C" int fb_memcpy_h2d_async(void *stream, void *d_dst, const void *h_src, size_t bytes)
+{
+    if (!d_dst || !h_src) return fail(FB_EINVAL, "fb_memcpy_h2d_async: NULL");
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return FB_OK;
+}
 
 // --------------------------------------------------------------------------------------------
 // pointwise launches

@@ -110,17 +110,11 @@ class EngineSlab:
         self.transport = "none"
         if world > 1:
             if transport == "rccl":
-                try:
-                    self._connect_rccl()
-                    self.transport = "rccl (engine: grouped ncclSend/ncclRecv)"
-                except B.FftBaroError as e:
-                    # LOUD second choice, never silent: the same bytes through torch.distributed's own point-to-point calls
-                    # (RCCL as well when the process group is nccl) behind the callback transport.  Reported in bench.py's line.
-                    import sys
-                    print("EngineSlab rank %d: engine RCCL transport unavailable (%s); using torch.distributed point-to-point behind "
-                          "the callback transport" % (rank, e), file=sys.stderr)
-                    self._connect_gloo()
-                    self.transport = "torch.distributed %s point-to-point (callback)" % dist.get_backend()
+                # All ranks or none: ncclCommInitRank is collective, so one rank that quietly took another transport would leave the
+                # others hanging in it.  The outcome of every step is agreed on over the process group; any failure raises on EVERY
+                # rank (there is no automatic second choice -- ask for transport="gloo" explicitly to rehearse without RCCL).
+                self._connect_rccl()
+                self.transport = "rccl (engine: grouped ncclSend/ncclRecv)"
             elif transport == "gloo":
                 self._connect_gloo()
                 self.transport = "torch.distributed %s point-to-point (callback)" % dist.get_backend()
@@ -137,16 +131,41 @@ class EngineSlab:
                 raise B.FftBaroError("EngineSlab: world > 1 needs transport='rccl', 'gloo' or a local hub handle")
 
     # -- transports
+    def _agree(self, ok, what):
+        """all_reduce(MIN) of a success flag over the process group: every rank learns whether ALL ranks got through `what`."""
+        torch, dist = self.torch, self.dist
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            raise self.B.FftBaroError("EngineSlab rank %d: %s failed on %s -- no rank connects" %
+                                      (self.rank, what, "this rank" if not ok else "another rank"))
+
     def _connect_rccl(self):
         torch, dist = self.torch, self.dist
         idbuf = C.create_string_buffer(128)
+        err = None
         if self.rank == 0:
-            self.B.check(self.L.fb_slab_unique_id(idbuf))
+            try:
+                self.B.check(self.L.fb_slab_unique_id(idbuf))
+            except self.B.FftBaroError as e:                  # rank 0 still takes part in the broadcast (a zero id) and in the vote below
+                err = e
+                idbuf = C.create_string_buffer(128)
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=dev)
         dist.broadcast(t, src=0)
+        if err is not None:
+            import sys
+            print("EngineSlab rank 0: cannot create the RCCL unique id: %s" % err, file=sys.stderr)
+        self._agree(err is None, "ncclGetUniqueId")
         raw = bytes(t.cpu().tolist())
-        self.B.check(self.L.fb_slab_connect_rccl(self._h, C.create_string_buffer(raw, 128)))
+        try:
+            self.B.check(self.L.fb_slab_connect_rccl(self._h, C.create_string_buffer(raw, 128)))
+        except self.B.FftBaroError as e:
+            import sys
+            print("EngineSlab rank %d: ncclCommInitRank failed: %s" % (self.rank, e), file=sys.stderr)
+            err = e
+        self._agree(err is None, "ncclCommInitRank")
 
     def _connect_gloo(self):
         torch, dist, world, rank = self.torch, self.dist, self.world, self.rank
