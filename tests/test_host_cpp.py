@@ -506,3 +506,96 @@ def test_comm_file_bootstrap_never_takes_a_stale_id(tmp_path):
     assert run("await", f, "", "1").stdout.strip() == "timeout"
     # 5. an over-long token is refused
     assert run("publish", f, "x" * 64, 1).returncode == 1
+
+
+LINKDIR = os.path.join(REFDIR, "linkcheck")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree is only present in the build container")
+def test_reference_sources_link_unmodified_against_the_boundary():
+    """the reference's own main.cpp, main-shallow-water.cpp and invert_pres.cpp -- unmodified, compiled where they
+    lie -- build with -I host/compat -I include and link with -lfftw3f_fb -lfieldio (oracle/Makefile `linkcheck`, outputs under
+    oracle/_ref/linkcheck/).  `#include <fftw3.h>` (main.cpp:12), `#include "fftwfop.cpp"` (main.cpp:19: the reference's own operator
+    class, on fftwf_malloc'ed memory) and the six FFTW entry points (main.cpp:103-135,154) resolve to the engine.  A link check of the
+    boundary, not an oracle: the FFT inside these binaries is the engine's."""
+    import xlab_fftbarotropic_amd as X
+    X.build_lib()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "linkcheck"])
+    for prog in ("main.out", "main-shallow-water.out", "invert_pres.out"):
+        exe = os.path.join(LINKDIR, prog)
+        assert os.access(exe, os.X_OK), prog
+        dyn = subprocess.run(["readelf", "-d", exe], stdout=subprocess.PIPE, text=True, check=True).stdout
+        assert "libfftw3f_fb.so" in dyn and "libfieldio.so" in dyn and "libfftw3f.so" not in dyn.replace("libfftw3f_fb", "")
+        syms = subprocess.run(["nm", "-D", "--undefined-only", exe], stdout=subprocess.PIPE, text=True, check=True).stdout
+        for name in ("fftwf_malloc", "fftwf_plan_dft_r2c_2d", "fftwf_plan_dft_c2r_2d", "fftwf_execute"):
+            assert name in syms, (prog, name)
+        assert "_Z10writeFieldPKcPfm" in syms or "_Z9readFieldPKcPfm" in syms, prog       # fieldio.hpp:5-6 by their C++ names
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "linkcheck", "main-shallow-water.out")), reason="oracle/_ref/linkcheck not built")
+def test_reference_pipeline_unmodified_runs_on_the_engine(tmp_path):
+    """The reference's own test (test/02-test_invert_pressure/example.sh) with the reference's own programs, none of them modified:
+    makefield-Kuo2004.out, vort_src_input.out and find_min.out as built into oracle/_ref from their sources, and main-shallow-water.out
+    and invert_pres.out built from theirs against the engine's FFTW-named boundary (oracle/_ref/linkcheck).  NPTS = 768, dt = 3 s,
+    1200 steps, the source switched on and off by the producer -- the configuration the reference ships.  Beside it the engine's own
+    driver (host/barotropic_main.out, fused path, same FIFO protocol) runs the same pipeline.  Compared: stdout's step lines, ./log,
+    every vort / psi / u / v / pres record and the find_min series (<= 1e-5), and the oracle at the first records.
+    What this pins: that a user of the reference can switch (the boundary is complete for the reference's own callers), and that the
+    oracle's restatement of main-shallow-water.cpp's loops agrees with the reference's compiled loops; the FFT on both sides is the
+    engine's, so it is no FFTW pin."""
+    import re
+    import oracle_py as O
+    import ref_numpy as R
+    _build()
+    n, dt = 768, 3.0
+    runs = {}
+    for tag in ("ref", "own"):
+        d = tmp_path / tag
+        (d / "input").mkdir(parents=True)
+        (d / "output").mkdir()
+        subprocess.check_call([os.path.join(REFDIR, "makefield-Kuo2004.out")], cwd=str(d), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        os.mkfifo(str(d / "vort_src_fifo"))
+        prod = subprocess.Popen("%s > vort_src_fifo" % os.path.join(REFDIR, "vort_src_input.out"), shell=True, cwd=str(d), stderr=subprocess.DEVNULL)
+        main = [os.path.join(LINKDIR, "main-shallow-water.out"), "-fvort_src_fifo"] if tag == "ref" else \
+               [os.path.join(HOST, "barotropic_main.out"), "-fvort_src_fifo"]
+        res = subprocess.run(main, cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        prod.wait(timeout=60)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = []
+        for ln in (d / "log").read_text().split():                                  # example.sh:15
+            mm = re.match(r"(.*/)psi(.*?\.bin)", ln)
+            if mm:
+                lines.append("%s=>%spres%s" % (ln, mm.group(1), mm.group(2)))
+        inv = [os.path.join(LINKDIR, "invert_pres.out")] if tag == "ref" else [os.path.join(HOST, "invert_pres.out")]
+        subprocess.run(inv, cwd=str(d), input="\n".join(lines) + "\n", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, text=True, check=True, timeout=600)
+        pres = sorted((f for f in os.listdir(str(d / "output")) if f.startswith("pres_step")), key=lambda f: int(re.findall(r"\d+", f)[0]))
+        fm = subprocess.run([os.path.join(REFDIR, "find_min.out")], cwd=str(d), input="".join("output/%s\n" % f for f in pres),
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, check=True)
+        runs[tag] = (res.stdout, (d / "log").read_text(), fm.stdout, len(pres))
+    steps_of = lambda out: [ln for ln in out.splitlines() if ln.startswith("# Step")]
+    assert steps_of(runs["ref"][0]) == steps_of(runs["own"][0]) and len(steps_of(runs["ref"][0])) == 1200
+    assert runs["ref"][1] == runs["own"][1] and runs["ref"][3] == 12
+    rd = lambda tag, f: np.fromfile(str(tmp_path / tag / "output" / f), dtype="<f4")
+    worst = 0.0
+    for step in range(0, 1200, 100):
+        for name in ("vort", "psi", "u", "v", "pres"):
+            a, b = rd("ref", "%s_step_%d.bin" % (name, step)), rd("own", "%s_step_%d.bin" % (name, step))
+            assert a.size == n * n
+            e = R.rel_l2(b, a)
+            worst = max(worst, e)
+            assert e < 1e-5, (name, step, e)
+        assert np.array_equal(rd("ref", "vort_src_input_step_%d.bin" % step), rd("own", "vort_src_input_step_%d.bin" % step)), step
+    print("reference pipeline on the engine vs the engine's own driver: worst record rel L2 %.2e" % worst)
+    fa = np.array([[float(x) for x in ln.split()] for ln in runs["ref"][2].splitlines() if ln.strip()])
+    fb = np.array([[float(x) for x in ln.split()] for ln in runs["own"][2].splitlines() if ln.strip()])
+    # "x y minimum" per line, the 30 lowest values of every file (find_min.cpp:67-101); which of two nearly equal minima comes first
+    # depends on the last bits, so the values are compared as sorted sets per file
+    assert fa.shape == fb.shape and fa.shape[0] == 12 * 30
+    for k in range(12):
+        assert np.allclose(np.sort(fa[30 * k:30 * k + 30, 2]), np.sort(fb[30 * k:30 * k + 30, 2]), rtol=1e-4, atol=0.0), k
+    # the oracle's restatement of the loop against the reference's compiled loop (FFT apart): the first two records
+    m = O.Model(n, n, dt=dt)
+    m.set_vort(np.fromfile(str(tmp_path / "ref" / "input" / "initial_vorticity.bin"), dtype="<f4").reshape(n, n))     # (the producer's source starts at step 2400)
+    m.step(100)
+    assert R.rel_l2(rd("ref", "vort_step_100.bin"), m.vort().ravel()) < 1e-5
