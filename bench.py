@@ -185,6 +185,13 @@ def main():
                      "transport": model.transport}
         if args.backend == "nccl" and not model.transport.startswith("rccl (engine"):
             raise SystemExit("bench.py: the multi-GPU line is only printed for the engine's RCCL transport, got %r" % model.transport)
+        # start-up check of the links before anything is timed: a known pattern through the transport, every word verified
+        wrong = model.transport_selftest()
+        tw = torch.tensor([wrong], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.int64)
+        dist.all_reduce(tw, op=dist.ReduceOp.SUM)
+        if int(tw.item()) != 0:
+            raise SystemExit("bench.py: the transport self-test found %d wrong words (rank %d: %d)" % (int(tw.item()), rank, wrong))
+        slab_info["transport_selftest"] = "ok"
         v0_local = torch.from_numpy(slab.local_rows(X.make_field(kind, n), rank, world)).cuda()
         if with_source:
             model.set_source_local(torch.from_numpy(slab.local_rows(X.make_source_kuo2004(n), rank, world)).cuda())

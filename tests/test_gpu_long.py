@@ -1,0 +1,126 @@
+"""BASELINE configs 4 and 5 at FULL size over a horizon, against committed oracle fixtures.
+
+The CPU side is tests/golden/oracle_8192_step300.npz and oracle_16384_src_step12.npz: the oracle (oracle/fb_oracle.c, the C
+restatement of main.cpp:146-317 / main-shallow-water.cpp:277-338) run in the build container by
+tests/golden/make_long_fixtures.py -- sub-sampled fields plus the full-field L2 norm and sum at the recorded steps.  Held to
+them, at the north-star bar of 1e-5 relative L2: the default single-GPU path (8192^2: k_rowh2 + k_col_full<., 2>; 16384^2:
+k_rowh<2> + the three-kernel x pass) and the multi-GPU schedule with all ranks racing as threads on this one GPU (4 ranks at
+8192^2, 8 at 16384^2: the kernels every rank runs on a real node).  Neither fixture is a reference output (no FFTW here:
+"parity unpinned" by the reference)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def _check(tag, v_sub, l2, tot, G, sub, step):
+    import ref_numpy as R
+    err = R.rel_l2(v_sub, G["vort_sub%d_step%d" % (sub, step)])
+    assert err < 1e-5, (tag, step, err)
+    assert abs(l2 / float(G["l2_step%d" % step]) - 1) < 1e-5, (tag, step)
+    # the sum is the (0,0) mode: conserved without a source, and fed by the source's mean with one
+    assert abs(tot / float(G["sum_step%d" % step]) - 1) < 1e-5, (tag, step)
+    return err
+
+
+def _stats(v):
+    """full-field sqrt(sum v^2) and sum v in float64, on the device"""
+    d = v.double()
+    return float(d.pow(2).sum().sqrt()), float(d.sum())
+
+
+def _ranks_run(n, world, dt, v0, script, sub):
+    """All `world` ranks of the engine-driven model as threads on this GPU.  script: [(steps, source or None or "keep"), ...];
+    after every segment each rank reports its sub-sampled rows and its share of sum v^2 and sum v."""
+    from test_gpu_slab import _slab, run_ranks
+    import torch
+    S = _slab()
+    hub = S.local_hub(world)
+
+    def rank_fn(r):
+        m = S.EngineSlab(n, n, dt=dt, rank=r, world=world, transport=hub)
+        try:
+            m.set_vort_local(S.local_rows(v0, r, world))
+            out = []
+            for steps, src in script:
+                if src is None:
+                    m.set_source_local(torch.zeros((m.XL, n), dtype=torch.float32, device="cuda"))      # the producer's "off" input is a field of zeros
+                elif not isinstance(src, str):
+                    m.set_source_local(S.local_rows(src, r, world))
+                m.step(steps)
+                v = m.vort_local()
+                d = v.double()
+                out.append((v[::sub, ::sub].cpu().numpy(), float(d.pow(2).sum()), float(d.sum())))
+                del v, d
+            return out
+        finally:
+            m.close()
+    try:
+        res = run_ranks(world, rank_fn)
+    finally:
+        S.local_hub_destroy(hub)
+    snaps = []
+    for k in range(len(script)):
+        snaps.append((np.concatenate([res[r][k][0] for r in range(world)], axis=0),
+                      float(np.sqrt(sum(res[r][k][1] for r in range(world)))), float(sum(res[r][k][2] for r in range(world)))))
+    return snaps
+
+
+def test_config4_8192_gaussian_300_steps_against_the_oracle_fixture():
+    """BASELINE configs[3]: 8192 x 8192 gaussian vortex (makefield-gaussian.cpp:14-31), dt = 0.375 s, steps 10 / 100 / 300 of
+    main.cpp:259-317: the default single-GPU path and the 4-rank ky-slab schedule, each against the oracle fixture."""
+    import xlab_fftbarotropic_amd as X
+    G = np.load(os.path.join(GOLD, "oracle_8192_step300.npz"))
+    n, dt, sub = 8192, 0.375, 32
+    v0 = X.make_field("gaussian", n)
+    m = X.Model(n, n, dt=dt)
+    m.set_vort(v0)
+    done, worst = 0, 0.0
+    for upto in (10, 100, 300):
+        m.step(upto - done)
+        done = upto
+        v = m.vort()
+        l2, tot = _stats(v)
+        worst = max(worst, _check("one GPU", v[::sub, ::sub].cpu().numpy(), l2, tot, G, sub, upto))
+        del v
+    del m
+    snaps = _ranks_run(n, 4, dt, v0, [(10, "keep"), (90, "keep"), (200, "keep")], sub)
+    for (vs, l2, tot), upto in zip(snaps, (10, 100, 300)):
+        worst = max(worst, _check("4 ranks", vs, l2, tot, G, sub, upto))
+    print("config 4, 300 steps: worst rel L2 against the oracle fixture %.2e" % worst)
+
+
+def test_config5_16384_source_forced_12_steps_against_the_oracle_fixture():
+    """BASELINE configs[4]: 16384 x 16384 Kuo2004 field through the source-forced loop (main-shallow-water.cpp:277-338) with the
+    FIFO producer's schedule (vort_src_input.cpp:35-61): the cake handed over before step 2, the field of zeros before step 6;
+    dt = 0.1875 s; records after steps 1, 5, 8 and 12.  The default single-GPU path and the 8-rank schedule against the fixture."""
+    import xlab_fftbarotropic_amd as X
+    G = np.load(os.path.join(GOLD, "oracle_16384_src_step12.npz"))
+    n, dt, sub = 16384, 0.1875, 64
+    assert int(G["on_step"]) == 2 and int(G["off_step"]) == 6
+    v0 = X.make_field("kuo2004", n)
+    src = X.make_source_kuo2004(n)
+    m = X.Model(n, n, dt=dt)
+    m.set_vort(v0)
+    worst = 0.0
+    for step in range(1, 13):
+        if step == 2:
+            m.set_source(src)
+        elif step == 6:
+            m.set_source(np.zeros((n, n), dtype=np.float32))
+        m.step(1)
+        if step in (1, 5, 8, 12):
+            v = m.vort()
+            l2, tot = _stats(v)
+            worst = max(worst, _check("one GPU", v[::sub, ::sub].cpu().numpy(), l2, tot, G, sub, step))
+            del v
+    del m
+    snaps = _ranks_run(n, 8, dt, v0, [(1, "keep"), (4, src), (3, None), (4, "keep")], sub)       # steps 1 | 2-5 | 6-8 | 9-12
+    for (vs, l2, tot), step in zip(snaps, (1, 5, 8, 12)):
+        worst = max(worst, _check("8 ranks", vs, l2, tot, G, sub, step))
+    print("config 5, 12 steps: worst rel L2 against the oracle fixture %.2e" % worst)

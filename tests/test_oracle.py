@@ -196,7 +196,7 @@ def test_single_fourier_mode_derivatives():
 
 
 # ---------------------------------------------------------------- FFT
-@pytest.mark.parametrize("n", [8, 15, 64, 768, 1024, 4096])
+@pytest.mark.parametrize("n", [8, 15, 64, 768, 1024, 4096, 8192, 16384])        # 8192 / 16384: the lengths the oracle checks configs 4 and 5 at
 def test_fft1d_vs_numpy(n):
     rng = np.random.default_rng(n)
     x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)

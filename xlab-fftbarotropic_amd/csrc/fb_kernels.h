@@ -175,6 +175,7 @@ struct RowArgs {
     RowView T;              // mixed-space output                                   (FUSED, FWD)
     int t_frozen;           // multi-GPU: 1 = also store the frozen columns of T (FWD: the state); FUSED: 0, their tendency is masked
     const float *src;       // vort_src (real [x][y]) or NULL                       (FUSED)
+    const int *src_nz;      // per local row: 1 = the row of vort_src holds a non-zero value; rows of zeros are not read (x + 0 == x)
     const float *rin;       // real input  [x][y]                                   (FWD)
     float *rout;            // real output [x][y]                                   (INV)
     int x0, nx;             // local rows [x0, x0 + nx), nx even (a row chunk of the pipelined multi-GPU step, else everything)
@@ -185,6 +186,17 @@ struct RowArgs {
     long sub_rows;
     const cf *tw_x;
 };
+
+// one workgroup per row of vort_src: does the row hold anything but zeros?  (The FIFO producer's cake covers a tenth of the rows,
+// and its "switch off" input is a field of zeros, vort_src_input.cpp:46,52-55: such rows cost the row pass no traffic.)
+__global__ void __launch_bounds__(256) k_src_row_flags(const float *__restrict__ src, int *__restrict__ flags, int ny)
+{
+    const float4 *row = reinterpret_cast<const float4 *>(src + (size_t)blockIdx.x * ny);
+    int any = 0;
+    for (int i = threadIdx.x; i < ny / 4; i += 256) { const float4 v = row[i]; any |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f); }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) flags[blockIdx.x] = any ? 1 : 0;
+}
 
 template <int N> struct RowCfg {
     static constexpr int T = N / 16;

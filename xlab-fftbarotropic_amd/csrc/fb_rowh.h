@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(512, RowH<V>::MIN_WAVES) k_rowh(RowArgs a, con
                     v[s][e] = cf_make(p[s][e].x - (v[s][e].x * a.scale) * zy[s][e].x, p[s][e].y - (v[s][e].y * a.scale) * zy[s][e].y);
         }
         const int tt = RH_LAUNDER(t), wl = tt >> 6, ll = tt & 63;
-        if (a.src) {                                                  // ... + vort_src (permuted order); the loads and their wait stay in this branch
+        if (a.src && a.src_nz[x]) {                                   // ... + vort_src (permuted order); the loads and their wait stay in this branch; rows of zeros are skipped
             const float2 *sp = reinterpret_cast<const float2 *>(a.src) + (size_t)x * M + tt;
 #pragma unroll
             for (int s = 0; s < V; ++s)
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(1024) k_rowh2(RowArgs a, const cf *__restrict_
             for (int e = 0; e < 8; ++e) v[e] = cf_make(p[e].x - (v[e].x * a.scale) * zy[e].x, p[e].y - (v[e].y * a.scale) * zy[e].y);
         }
         const int tt = launder(t), wl = tt >> 6, ll = tt & 63;
-        if (a.src) {
+        if (a.src && a.src_nz[xrow]) {
             const float2 *sp = reinterpret_cast<const float2 *>(a.src) + (size_t)xrow * M + tt;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float2 q = sp[e * 512]; v[e].x += q.x; v[e].y += q.y; }

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256, 4) k_rowq(RowArgs a, const float4 *__rest
                            : cf_make(p[e].x - (v[e].x * a.scale) * zy[e].x, p[e].y - (v[e].y * a.scale) * zy[e].y);
         }
         const int tt = RQ_LAUNDER2(t);
-        if (a.src) {                                                  // + vort_src (permuted order)
+        if (a.src && a.src_nz[x]) {                                   // + vort_src (permuted order); rows of zeros are skipped
             const float2 *sp = reinterpret_cast<const float2 *>(a.src) + (size_t)x * M + tt;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float2 q = sp[e * 256]; v[e].x += q.x; v[e].y += q.y; }

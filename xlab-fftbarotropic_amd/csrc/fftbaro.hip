@@ -743,13 +743,21 @@ static int autotune_pitch(fb_ctx *c)
     if ((size_t)c->nx * c->P * sizeof(cf) < ((size_t)32 << 20)) return FB_OK;      // cache-resident grids: nothing to gain
     const int nsub = full_pass_nsub(c);
     const int P0 = c->P, NC = nsub ? 7 : 4;                                        // create_impl leaves room for P0 + 96
-    if (nsub && !getenv("FB_PITCH_TUNE")) {
+    constexpr int PITCH_HEADROOM = 96, RULE_EXTRA = 32;                            // the coefficient tables hold P0 + PITCH_HEADROOM columns
+    static_assert(RULE_EXTRA <= PITCH_HEADROOM && 16 * (7 - 1) <= PITCH_HEADROOM, "pitch candidates must fit the table head-room of create_impl");
+    if ((int)c->h_gy.size() < P0 + PITCH_HEADROOM) return fail(FB_EINVAL, "autotune_pitch: coefficient tables shorter than the pitch candidates");
+    // The fixed rule below was measured on MI355X (gfx950): the pitch's effect comes from that part's memory-controller address
+    // hash.  On any other device the interleaved probe decides instead.
+    hipDeviceProp_t prop;
+    int dev = 0;
+    const bool is_gfx950 = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    if (nsub && is_gfx950 && !getenv("FB_PITCH_TUNE")) {
         // single-pass x transform: a fixed rule.  tools/pitch_scan.sh on three boxes: round16(ny/2 + 1) is the slowest pitch at
         // 4096^2 (k_col_full 0.1525-0.1556 ms against 0.148-0.152 for every other candidate) and, with + 16, at 8192^2 (0.75 / 0.79 ms
         // against 0.65-0.69 for + 32, + 64, + 96 and 0.69-0.72 for + 48, + 80).  The probe below (FB_PITCH_TUNE=1) sees the same
         // ordering on average but not reliably in one process: its buffers land on other physical pages than the model's, which
         // moves a candidate by up to 5 % at 8192^2, more than what separates the good pitches.
-        c->P = c->KA = c->katot = c->grp[0].ncols = P0 + 32;
+        c->P = c->KA = c->katot = c->grp[0].ncols = P0 + RULE_EXTRA;
         finish_groups(c);
         return FB_OK;
     }
@@ -943,6 +951,7 @@ struct fb_model {
     hipGraphExec_t graph_exec;
     const float *graph_src; hipStream_t graph_stream;
     float *src;                      // vort_src (this rank's rows) or NULL (== zeros)
+    int *src_nz;                     // per row of src: 1 = holds a non-zero value (k_src_row_flags)
     cf *nat[3];                      // natural-layout temporaries for the record path (lazy)
     // 0: derivative fields stale; 1: w4_send holds the derivatives with the backward x pass finished on the frozen
     // tiles only (the backward strided pass on the active tiles comes next); 2: finished on every tile (ready for the row pass)
@@ -1008,6 +1017,7 @@ extern "C" int fb_model_destroy(fb_model *m)
     }
     model_drop_graph(m);
     if (m->src) hipFree(m->src);
+    if (m->src_nz) hipFree(m->src_nz);
     for (auto p : m->nat) if (p) hipFree(p);
     delete m;
     return FB_OK;
@@ -1053,6 +1063,9 @@ extern "C" int fb_model_set_source(fb_model *m, const float *d_src)
     const size_t n = (size_t)c->XL * c->ny * sizeof(float);       // the caller's local rows
     if (!d_src) { if (m->src) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(m->src); m->src = nullptr; } return FB_OK; }
     if (!m->src && hipMalloc((void **)&m->src, n) != hipSuccess) return fail(FB_ENOMEM, "source allocation failed");
+    if (!m->src_nz && hipMalloc((void **)&m->src_nz, (size_t)c->XL * sizeof(int)) != hipSuccess) return fail(FB_ENOMEM, "source allocation failed");
+    hipLaunchKernelGGL(k_src_row_flags, dim3(c->XL), dim3(256), 0, c->stream, d_src, m->src_nz, c->ny);
+    HIPCHK(hipGetLastError());
     if (c->use_rowq) {                                            // k_rowq reads vort_src in its own physical-space order
         hipLaunchKernelGGL(k_rowq_permute_src, dim3(grid_for(c, (size_t)c->XL * c->ny / 2)), dim3(256), 0, c->stream, d_src, m->src, c->XL);
         HIPCHK(hipGetLastError());
@@ -1168,7 +1181,7 @@ static RowArgs fused_row_args(fb_model *m, int x0, int nrows)
     RowArgs a = row_args_base(c);
     if (c->world == 1) { a.M = view_single(c, m->gb[0].w4_recv, (long)priv_elems(c)); a.T = view_single(c, m->gb[0].t_send, 0); }
     else { a.M = view_slab(c, m->gb[0].w4_recv, m->gb[1].w4_recv, 4); a.T = view_slab(c, m->gb[0].t_send, m->gb[1].t_send, 1); a.t_frozen = 0; }
-    a.src = m->src; a.scale = 1.0f / (float)((size_t)c->nx * c->ny); a.x0 = x0; a.nx = nrows; a.prescaled = m->prescale ? 1 : 0;
+    a.src = m->src; a.src_nz = m->src_nz; a.scale = 1.0f / (float)((size_t)c->nx * c->ny); a.x0 = x0; a.nx = nrows; a.prescaled = m->prescale ? 1 : 0;
     return a;
 }
 // forward x pass of the tendency + RK stage update + derivatives of the new stage state (three-kernel path)

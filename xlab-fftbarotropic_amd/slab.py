@@ -232,6 +232,13 @@ class EngineSlab:
         self.synchronize()
         return psi, u, v
 
+    def transport_selftest(self, count=1 << 18):
+        """A known pattern of world*count floats through the connected transport; returns the number of wrong words (0 = links fine).
+        Collective: every rank calls it."""
+        bad = C.c_size_t()
+        self.B.check(self.L.fb_slab_transport_selftest(self._h, count, C.byref(bad)))
+        return int(bad.value)
+
     def time_steps(self, n):
         ms = C.c_float()
         self.B.check(self.L.fb_slab_time_steps(self._h, n, C.byref(ms)))
