@@ -215,9 +215,15 @@ int fb_slab_info(fb_slab *s, int *rows_local, int *cols_active, int *cols_frozen
                  int *field_groups, int *row_chunks);
 /* host logic, no GPU needed: XL, KA, KF of a decomposition */
 int fb_slab_geometry(int nx, int ny, int world, int *rows_local, int *cols_active, int *cols_frozen);
+/* host logic, no GPU needed: the column groups a rank's active columns are cut into (1, or 2 where a stage is pipelined by
+ * column groups: BASELINE configs 4 and 5); cols2[g] = columns per rank of group g (0 for an absent group): a rank's active
+ * slab [rank*KA, (rank+1)*KA) is cut locally, its first cols2[0] columns are group 0 */
+int fb_slab_col_groups(int nx, int ny, int world, int *ngroups, int *cols2);
 /* host logic, no GPU needed: the operations of ONE RK stage in issue order, ops[i] = 16*kind + argument, kind =
- * 1 backward x sub-pass of field group g, 2 all-to-all of field group g, 3 row pass of row chunk h, 4 all-to-all of
- * tendency chunk h, 5 forward x pass + RK update.  Returns the number of operations (negative never; 0 on error). */
+ * 1 backward x sub-pass of field group g, 2 all-to-all of the derivative fields (field group g; column group g when
+ * pipelined by column groups), 3 row pass of row chunk h, 4 all-to-all of tendency chunk h (every column group), 5 forward x
+ * pass + RK update (of column group g), 6 backward x sub-pass of all four fields of column group g.
+ * Returns the number of operations (negative never; 0 on error). */
 int fb_slab_plan(int nx, int ny, int world, int *field_groups, int *row_chunks, int *ops, int cap);
 /* lower level: a context bound to one rank's slabs (the operator / FFT entry points above need world == 1) */
 int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, int rank, int world);

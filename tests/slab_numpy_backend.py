@@ -2,7 +2,8 @@
 xlab-fftbarotropic_amd/slab.py under gloo.  TEST INFRASTRUCTURE: not part of the product.
 
 Buffer layouts are the engine's (include/fftbaro.h "Multi-GPU", csrc/fftbaro.hip GroupBufs), per column group g
-(0 = this rank's slab of the ACTIVE ky columns, 1 = its slab of the FROZEN ones):
+(0 .. nact-1 = this rank's slabs of the ACTIVE ky columns -- two where a stage is pipelined by column groups --, the last one
+= its slab of the FROZEN ones):
     w4_send[g] [dst][4][XL][ncols_g]    w4_recv[g] [src][4][XL][ncols_g]
     t_send[g]  [dst][XL][ncols_g]       t_recv[g]  [nx][ncols_g]
 The double is deliberately lazy the way the engine is: a field only reaches w4_send when col_bwd() is asked for it and a
@@ -20,10 +21,17 @@ class NumpyBackend:
         slab = import_module("xlab-fftbarotropic_amd.slab")
         self.nx, self.ny, self.hy, self.rank, self.world = nx, ny, ny // 2 + 1, rank, world
         self.XL, self.KA, self.KF = slab.slab_geometry(nx, ny, world)
-        self.ncols = [self.KA, self.KF]
+        act = slab.slab_col_groups(nx, ny, world)
+        self.nact = len(act)
+        self.ncols = act + ([self.KF] if self.KF else [])
+        self.ngroups = len(self.ncols)
         self.katot = world * self.KA
         self.ktot = self.katot + world * self.KF                        # >= hy: columns beyond hy are padding
-        self.ky = [np.arange(rank * self.KA, (rank + 1) * self.KA), self.katot + np.arange(rank * self.KF, (rank + 1) * self.KF)]
+        # a rank's active slab [rank*KA, (rank+1)*KA) is cut locally into the active groups; frozen slabs follow the active columns
+        self.off = [sum(act[:g]) for g in range(self.nact)] + ([0] if self.KF else [])
+        self.slab = [self.KA] * self.nact + ([self.KF] if self.KF else [])             # slab width of the group's segment
+        self.seg0 = [0] * self.nact + ([self.katot] if self.KF else [])                # first global column of the segment
+        self.ky = [self.seg0[g] + rank * self.slab[g] + self.off[g] + np.arange(n) for g, n in enumerate(self.ncols)]
         gx, gy, lap, lapi, mask = R.tables(nx, ny, Lx, Ly)
         padc = lambda a, fill: np.concatenate([a.astype(np.float64), np.full((nx, self.ktot - self.hy), fill)], axis=1)
         self.ikx = 1j * gx.astype(np.float64)[:, None]
@@ -33,7 +41,7 @@ class NumpyBackend:
         self.lap = [lap_p[:, k] for k in self.ky]
         self.lapi = [lapi_p[:, k] for k in self.ky]
         self.mask = [mask_p[:, k] for k in self.ky]
-        assert not self.mask[1].any(), "the frozen slab must hold masked modes only"
+        assert not self.KF or not self.mask[self.nact].any(), "the frozen slab must hold masked modes only"
         self.nu, self.dt = float(np.float32(nu)), float(np.float32(dt))
         z = lambda n: torch.zeros(n, dtype=torch.complex128)
         self.w4_send = [z(4 * nx * n) for n in self.ncols]
@@ -44,8 +52,8 @@ class NumpyBackend:
             self.w4_recv = [z(4 * nx * n) for n in self.ncols]
             self.t_recv = [z(nx * n) for n in self.ncols]
         self.Z = [np.zeros((nx, n), dtype=np.complex128) for n in self.ncols]       # vort_c, [kx][local ky]
-        self.Z0 = self.Zc = self.acc = None
-        self.pending = None                                                           # group 0: x-transformed derivative fields not yet in w4_send
+        self.Z0, self.Zc, self.acc = [None] * self.nact, [None] * self.nact, [None] * self.nact
+        self.pending = [None] * self.nact                                             # active groups: x-transformed derivative fields not yet in w4_send
         self.src = np.zeros((self.XL, ny))
 
     # helpers ------------------------------------------------------------------------------
@@ -59,42 +67,45 @@ class NumpyBackend:
         return np.ascontiguousarray(fields_x.reshape(4, self.world, self.XL, n).transpose(1, 0, 2, 3)).reshape(-1)
 
     def _rows(self, bufs, nfields, f):
-        """field f of the row-side buffers of both groups -> [XL][hy]"""
-        parts = []
-        for g in (0, 1):
-            if self.ncols[g]:
-                blk = bufs[g].numpy().reshape(self.world, nfields, self.XL, self.ncols[g])[:, f]       # [src][XL][ncols]
-                parts.append(np.concatenate(list(blk), axis=1))
-        return np.concatenate(parts, axis=1)[:, :self.hy]
+        """field f of the row-side buffers of every group -> [XL][hy]"""
+        full = np.zeros((self.XL, self.ktot), dtype=np.complex128)
+        for g, n in enumerate(self.ncols):
+            if n:
+                blk = bufs[g].numpy().reshape(self.world, nfields, self.XL, n)[:, f]                   # [src][XL][ncols]
+                for s_ in range(self.world):
+                    c0 = self.seg0[g] + s_ * self.slab[g] + self.off[g]
+                    full[:, c0:c0 + n] = blk[s_]
+        return full[:, :self.hy]
 
     def _rows_to_t(self, rows_spec, x0, frozen):
         """half-spectrum rows [nrows][hy] of local rows x0.. -> t_send, blocked by destination rank"""
         nrows = rows_spec.shape[0]
         full = np.concatenate([rows_spec, np.zeros((nrows, self.ktot - self.hy), dtype=np.complex128)], axis=1)
-        for g in ((0, 1) if frozen else (0,)):
+        for g in range(self.ngroups if frozen else self.nact):
             n = self.ncols[g]
             if not n:
                 continue
-            base = 0 if g == 0 else self.katot
             view = self.t_send[g].numpy().reshape(self.world, self.XL, n)
             for d in range(self.world):
-                view[d, x0:x0 + nrows] = full[:, base + d * n:base + (d + 1) * n]
+                c0 = self.seg0[g] + d * self.slab[g] + self.off[g]
+                view[d, x0:x0 + nrows] = full[:, c0:c0 + n]
 
     # phases (names follow csrc/fb_slab_driver.h) -------------------------------------------
     def prime(self):
-        for g in (0, 1):
+        for g in range(self.ngroups):
             if not self.ncols[g]:
                 continue
             cols = np.fft.ifft(self._derive(self.Z[g], g), axis=1) * self.nx                       # [4][x][ncols]
-            if g == 0:
-                self.pending = cols
-                self.w4_send[0].zero_()
+            if g < self.nact:
+                self.pending[g] = cols
+                self.w4_send[g].zero_()
             else:
-                self.w4_send[1].numpy()[:] = self._blocked(cols, 1)                                # frozen columns: final, sent once
+                self.w4_send[g].numpy()[:] = self._blocked(cols, g)                                # frozen columns: final, sent once
 
-    def col_bwd(self, f0, f1):
-        view = self.w4_send[0].numpy().reshape(self.world, 4, self.XL, self.KA)
-        view[:, f0:f1] = self.pending[f0:f1].reshape(f1 - f0, self.world, self.XL, self.KA).transpose(1, 0, 2, 3)
+    def col_bwd(self, f0, f1, g=0):
+        n = self.ncols[g]
+        view = self.w4_send[g].numpy().reshape(self.world, 4, self.XL, n)
+        view[:, f0:f1] = self.pending[g][f0:f1].reshape(f1 - f0, self.world, self.XL, n).transpose(1, 0, 2, 3)
 
     def row(self, x0, nrows):
         nx, ny = self.nx, self.ny
@@ -103,36 +114,36 @@ class NumpyBackend:
         t = -u * dzdx - v * dzdy + self.src[x0:x0 + nrows]                                        # main.cpp:225-227
         self._rows_to_t(np.fft.rfft(t, axis=1), x0, frozen=False)
 
-    def col_fwd(self, stage):
+    def col_fwd(self, stage, g=0):
         nx = self.nx
-        That = np.fft.fft(self.t_recv[0].numpy().reshape(nx, self.KA), axis=0)
+        That = np.fft.fft(self.t_recv[g].numpy().reshape(nx, self.ncols[g]), axis=0)
         if stage == 0:
-            self.Z0, self.Zc = self.Z[0], self.Z[0]
-        k = (That + self.Zc * self.lap[0] * self.nu) * self.mask[0]                              # main.cpp:148,240-243,296
+            self.Z0[g], self.Zc[g] = self.Z[g], self.Z[g]
+        k = (That + self.Zc[g] * self.lap[g] * self.nu) * self.mask[g]                          # main.cpp:148,240-243,296
         dt = self.dt
         if stage == 0:
-            self.acc = k; self.Zc = self.Z0 + k * (dt / 2)
+            self.acc[g] = k; self.Zc[g] = self.Z0[g] + k * (dt / 2)
         elif stage == 1:
-            self.acc = self.acc + 2 * k; self.Zc = self.Z0 + k * (dt / 2)
+            self.acc[g] = self.acc[g] + 2 * k; self.Zc[g] = self.Z0[g] + k * (dt / 2)
         elif stage == 2:
-            self.acc = self.acc + 2 * k; self.Zc = self.Z0 + k * dt
+            self.acc[g] = self.acc[g] + 2 * k; self.Zc[g] = self.Z0[g] + k * dt
         else:
-            self.Z[0] = self.Z0 + (self.acc + k) * dt / 6; self.Zc = self.Z[0]
-        self.pending = np.fft.ifft(self._derive(self.Zc, 0), axis=1) * nx
-        self.t_recv[0].zero_()                                                                   # consumed: a stale re-read would show
+            self.Z[g] = self.Z0[g] + (self.acc[g] + k) * dt / 6; self.Zc[g] = self.Z[g]
+        self.pending[g] = np.fft.ifft(self._derive(self.Zc[g], g), axis=1) * nx
+        self.t_recv[g].zero_()                                                                   # consumed: a stale re-read would show
         if self.world > 1:
-            self.w4_send[0].zero_()
+            self.w4_send[g].zero_()
 
     def r2c_rows(self, real_rows):
         self._rows_to_t(np.fft.rfft(np.asarray(real_rows, dtype=np.float64), axis=1), 0, frozen=True)
 
     def r2c_cols(self):
-        for g in (0, 1):
+        for g in range(self.ngroups):
             if self.ncols[g]:
                 self.Z[g] = np.fft.fft(self.t_recv[g].numpy().reshape(self.nx, self.ncols[g]), axis=0)
 
     def c2r_cols(self):
-        for g in (0, 1):
+        for g in range(self.ngroups):
             if self.ncols[g]:
                 cols = np.fft.ifft(self.Z[g], axis=0) * self.nx                                   # [x][ncols] == [dst][XL][ncols]
                 self.t_recv[g].numpy()[:] = np.ascontiguousarray(cols).reshape(-1)

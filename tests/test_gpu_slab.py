@@ -81,6 +81,9 @@ def slab_run(n, world, steps, v0, dt, src=None, ny=None, env=None):
     (1, 256, 3, None), (2, 256, 3, None), (4, 256, 2, None), (8, 512, 1, None), (2, 1024, 2, None), (4, 768, 2, None),
     (4, 1024, 2, {"FB_SLAB_FIELD_GROUPS": "4", "FB_SLAB_ROW_CHUNKS": "4"}),       # finest pipelining on a small grid
     (2, 512, 2, {"FB_SLAB_FIELD_GROUPS": "2", "FB_SLAB_ROW_CHUNKS": "8"}),
+    (2, 512, 3, {"FB_SLAB_COL_GROUPS": "2"}),                                     # the stage pipelined by column groups (configs 4 and 5 take this path)
+    (4, 1024, 2, {"FB_SLAB_COL_GROUPS": "2", "FB_SLAB_ROW_CHUNKS": "4"}),
+    (8, 512, 2, {"FB_SLAB_COL_GROUPS": "2", "FB_SLAB_ROW_CHUNKS": "2"}),
 ])
 def test_engine_slab_matches_fused_path(world, n, steps, env):
     import xlab_fftbarotropic_amd as X
@@ -94,8 +97,10 @@ def test_engine_slab_matches_fused_path(world, n, steps, env):
     ref.step(steps)
     want = ref.vort().cpu().numpy()
     back, got, plan = slab_run(n, world, steps, v0, dt, src=src, env=env)
-    if env:
+    if env and "FB_SLAB_FIELD_GROUPS" in env:
         assert plan[0] == int(env["FB_SLAB_FIELD_GROUPS"]) and plan[1] <= int(env["FB_SLAB_ROW_CHUNKS"])
+    if env and "FB_SLAB_COL_GROUPS" in env:
+        assert plan[0] == 1 and plan[1] <= int(env.get("FB_SLAB_ROW_CHUNKS", "1"))
     assert np.array_equal(back.view(np.uint32), back_want.view(np.uint32))            # set_vort / get_vort across the transposes
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
@@ -154,7 +159,7 @@ def test_config4_8192_gaussian_on_4_ranks_full_size():
     want = ref.vort().cpu().numpy()
     del ref
     back, got, plan = slab_run(n, world, 1, v0, dt)
-    assert plan == (4, 1, 976, 64)                                                    # fields pipelined (26 us of sub-pass each), rows not (84 us in all)
+    assert plan == (1, 1, 976, 64)                                                    # pipelined by the two column groups (496 + 480 columns), rows not (84 us in all)
     assert R.rel_l2(back, v0) < 1e-6
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert R.rel_l2(got, want_default) < 2e-6                                         # same maths, another factorisation of the x transform
@@ -193,13 +198,14 @@ def test_config5_16384_source_forced_on_8_ranks_full_size():
     gain = (want.astype(np.float64) - unforced.astype(np.float64)).sum() / (src.astype(np.float64).sum() * dt)
     assert abs(gain - 1.0) < 1e-3                                                     # d(mean vort)/dt = mean source
     back, got, plan = slab_run(n, world, 1, v0, dt, src=src)
-    assert plan == (4, 2, 976, 64)
+    assert plan == (1, 2, 976, 64)                                                    # two column groups, two row chunks
     assert R.rel_l2(back, v0) < 1e-6
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     _invariants(v0, got, with_source=True)
 
 
 @pytest.mark.parametrize("n,world,steps,env", [(512, 4, 40, {"FB_SLAB_FIELD_GROUPS": "4", "FB_SLAB_ROW_CHUNKS": "2"}),
+                                               (512, 4, 40, {"FB_SLAB_COL_GROUPS": "2", "FB_SLAB_ROW_CHUNKS": "2"}),
                                                (4096, 4, 8, {"FB_SLAB_FIELD_GROUPS": "4", "FB_SLAB_ROW_CHUNKS": "4"}),
                                                (4096, 8, 6, None),
                                                (4096, 8, 6, {"FB_SLAB_TWO_STREAMS": "1"}),

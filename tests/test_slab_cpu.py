@@ -25,7 +25,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, steps, with_src, out_path):
+def _worker(rank, world, port, n, steps, with_src, out_path, env=None):
+    os.environ.update(env or {})
     for p in (ROOT, HERE, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -64,11 +65,13 @@ def _worker(rank, world, port, n, steps, with_src, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,steps,with_src", [(2, 64, 3, False), (2, 64, 2, True), (4, 64, 2, False), (2, 256, 1, True)])
-def test_slab_exchange_matches_single_process(tmp_path, world, n, steps, with_src):
+@pytest.mark.parametrize("world,n,steps,with_src,env", [(2, 64, 3, False, None), (2, 64, 2, True, None), (4, 64, 2, False, None), (2, 256, 1, True, None),
+                                                          (2, 256, 2, True, {"FB_SLAB_COL_GROUPS": "2"}),      # the stage pipelined by column groups
+                                                          (4, 128, 2, False, {"FB_SLAB_COL_GROUPS": "2"})])
+def test_slab_exchange_matches_single_process(tmp_path, world, n, steps, with_src, env):
     port = _free_port()
     out = str(tmp_path / "err_%d.npy")
-    mp.spawn(_worker, args=(world, port, n, steps, with_src, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, steps, with_src, out, env), nprocs=world, join=True)
     for r in range(world):
         err0, err = np.load(out % r)
         assert err0 < 1e-12, "c2r(r2c(x)) across the transposes, rank %d" % r
@@ -96,6 +99,10 @@ def test_slab_geometry_plan_and_world1():
         assert (xl.value, ka.value, kf.value) == slab.slab_geometry(nx, ny, w), (nx, ny, w)
         fg, ch, ops = slab.engine_plan(nx, ny, w)
         assert (fg, ch) == slab.stage_plan(nx, ny, w) and ops == slab.stage_schedule(nx, ny, w), (nx, ny, w)
+        ng, cols = C.c_int(), (C.c_int * 2)()
+        assert L.fb_slab_col_groups(nx, ny, w, C.byref(ng), cols) == 0
+        groups = slab.slab_col_groups(nx, ny, w)
+        assert [cols[g] for g in range(ng.value)] == groups and sum(groups) == ka.value and all(g % 16 == 0 and g > 0 for g in groups), (nx, ny, w)
         hy = ny // 2 + 1
         assert w * ka.value + w * kf.value >= hy and ka.value % 16 == 0 and kf.value % 16 == 0
         # every column inside the dealiasing circle lies in an active slab, and the last rank is not idle:
@@ -107,8 +114,13 @@ def test_slab_geometry_plan_and_world1():
     assert slab.slab_geometry(8192, 8192, 4) == (2048, 976, 64)
     assert slab.slab_geometry(16384, 16384, 8) == (2048, 976, 64)
     assert slab.slab_geometry(4096, 4096, 8) == (512, 256, 16)
-    assert slab.stage_plan(8192, 8192, 4) == (4, 1) and slab.stage_plan(16384, 16384, 8) == (4, 2)
-    assert slab.stage_plan(4096, 4096, 2) == (2, 1) and slab.stage_plan(4096, 4096, 8) == (1, 1) and slab.stage_plan(4096, 4096, 1) == (1, 1)
+    # configs 4 and 5 and the headline grid on two ranks are pipelined by column groups (a group's four fields leave together);
+    # smaller slabs keep one group and cut the derivative exchange by fields where that pays
+    assert slab.slab_col_groups(8192, 8192, 4) == [496, 480] and slab.slab_col_groups(16384, 16384, 8) == [496, 480]
+    assert slab.slab_col_groups(4096, 4096, 2) == [496, 480] and slab.slab_col_groups(4096, 4096, 4) == [496] and slab.slab_col_groups(4096, 4096, 8) == [256]
+    assert slab.stage_plan(8192, 8192, 4) == (1, 1) and slab.stage_plan(16384, 16384, 8) == (1, 2)
+    assert slab.stage_plan(4096, 4096, 2) == (1, 1) and slab.stage_plan(4096, 4096, 4) == (1, 1) and slab.stage_plan(4096, 4096, 8) == (1, 1) and slab.stage_plan(4096, 4096, 1) == (1, 1)
+    assert [k for k, _ in slab.stage_schedule(16384, 16384, 8)] == [3, 4, 3, 4, 5, 6, 2, 5, 6, 2]
     assert L.fb_slab_plan(1000, 1000, 2, None, None, None, 0) == 0             # unsupported grid
     n = 32
     rng = np.random.default_rng(0)

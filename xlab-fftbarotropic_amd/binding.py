@@ -122,7 +122,7 @@ EXPORTS = [
     "fb_model_time_steps", "fb_model_profile_steps", "fb_write_field", "fb_read_field", "fb_make_field", "fb_make_source_kuo2004",
     "fb_create_slab", "fb_slab_unique_id", "fb_slab_create", "fb_slab_destroy", "fb_slab_connect_rccl", "fb_local_hub_create",
     "fb_local_hub_destroy", "fb_slab_connect_local", "fb_slab_connect_callback", "fb_slab_set_vort_local", "fb_slab_set_source_local",
-    "fb_slab_get_vort_local", "fb_slab_get_diag_local", "fb_slab_step", "fb_slab_synchronize", "fb_slab_time_steps", "fb_slab_transport_selftest", "fb_slab_info", "fb_slab_geometry", "fb_slab_plan",
+    "fb_slab_get_vort_local", "fb_slab_get_diag_local", "fb_slab_step", "fb_slab_synchronize", "fb_slab_time_steps", "fb_slab_transport_selftest", "fb_slab_info", "fb_slab_geometry", "fb_slab_plan", "fb_slab_col_groups",
     "fb_malloc_host", "fb_free_host", "fb_stream_create", "fb_stream_destroy", "fb_stream_synchronize", "fb_event_create",
     "fb_event_destroy", "fb_event_record", "fb_stream_wait_event", "fb_event_synchronize", "fb_memcpy_d2h_async", "fb_memcpy_h2d_async", "fb_slab_record_event", "fb_slab_wait_event",
 ]

@@ -20,7 +20,7 @@ LIB_FIELDIO = os.path.join(LIBDIR, "libfieldio.so")
 LIB_FFTW = os.path.join(LIBDIR, "libfftw3f_fb.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXX = os.environ.get("CXX", "g++")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=on",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value"]
 LINK = ["-ldl"]          # RCCL (the multi-GPU transposes) is dlopen'ed on first use, not linked
 

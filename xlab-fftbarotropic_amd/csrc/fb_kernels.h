@@ -158,18 +158,20 @@ __global__ void __launch_bounds__(256) k_state_relayout(const cf *__restrict__ i
 enum { ROW_FUSED = 0, ROW_INV = 1, ROW_FWD = 2 };
 
 // A mixed-space array as the row pass sees it: element (field, row, k), k = global ky in [0, ny/2].
-// One GPU: one segment of pitch ka.  Multi-GPU exchange buffers: the row is cut into ky slabs of `ka` columns
-// (the ACTIVE columns, ky < katot = world*ka, exchanged every RK stage) followed by slabs of `kf` columns (the
-// FROZEN columns beyond the dealiasing circle, SURVEY note N1, exchanged once); slab s of a segment lives sstr*
-// complex after slab 0.  Divisions by ka / kf are multiplications by mag* = floor(2^32/d) + 1 (exact for k*d < 2^32).
+// One GPU: one segment of pitch ka.  Multi-GPU exchange buffers: the row is cut into ky slabs of `ka` columns (the ACTIVE
+// columns, ky < katot = world*ka, exchanged every RK stage) followed by slabs of `kf` columns (the FROZEN columns beyond the
+// dealiasing circle, SURVEY note N1, exchanged once).  Where the stage is pipelined by column groups (fb_slab_driver.h) an
+// active slab is held in two buffers: its first ka0 columns in segment a (pitch ka0), the other kb = ka - ka0 in segment b
+// (pitch kb); kb == 0: one buffer, ka0 == ka.  Slab s of a segment lives sstr* complex after slab 0.  Divisions by ka / kf
+// are multiplications by mag* = floor(2^32/d) + 1 (exact for k*d < 2^32).
 struct RowView {
-    const cf *a, *f;        // segment bases (field 0): active / frozen
-    long fstrA, fstrF;      // field strides (complex)
-    long sstrA, sstrF;      // slab strides (complex); unused on one GPU
-    int ka, kf, katot;      // one GPU: ka = pitch
+    const cf *a, *b, *f;        // segment bases (field 0): active columns [0, ka0) of a slab / [ka0, ka) / frozen
+    long fstrA, fstrB, fstrF;   // field strides (complex)
+    long sstrA, sstrB, sstrF;   // slab strides (complex); unused on one GPU
+    int ka, ka0, kb, kf;        // one GPU: ka = ka0 = pitch
+    int katot;
     unsigned magA, magF;
 };
-
 struct RowArgs {
     RowView M;              // mixed-space inputs                                   (FUSED: 4 fields, INV: 1)
     RowView T;              // mixed-space output                                   (FUSED, FWD)
@@ -222,8 +224,13 @@ FB_DEV const cf *row_ptr(const RowView &v, int field, int row, int k)
 {
     if (!SLAB) return v.a + (size_t)field * v.fstrA + (size_t)row * v.ka + k;
     if (k < v.katot) {
-        const int s = (int)__umulhi((unsigned)k, v.magA);
-        return v.a + (size_t)field * v.fstrA + (size_t)s * v.sstrA + (size_t)row * v.ka + (k - s * v.ka);
+        const int s = (int)__umulhi((unsigned)k, v.magA), w = k - s * v.ka;          // slab (peer rank), column within the slab
+        if (v.kb == 0) return v.a + (size_t)field * v.fstrA + (size_t)s * v.sstrA + (size_t)row * v.ka + w;      // (uniform) one column group
+        const bool inb = w >= v.ka0;
+        const cf *base = inb ? v.b : v.a;
+        const long fstr = inb ? v.fstrB : v.fstrA, sstr = inb ? v.sstrB : v.sstrA;
+        const int kc = inb ? v.kb : v.ka0, wc = inb ? w - v.ka0 : w;
+        return base + (size_t)field * fstr + (size_t)s * sstr + (size_t)row * kc + wc;
     }
     const int kk = k - v.katot, s = (int)__umulhi((unsigned)kk, v.magF);
     return v.f + (size_t)field * v.fstrF + (size_t)s * v.sstrF + (size_t)row * v.kf + (kk - s * v.kf);

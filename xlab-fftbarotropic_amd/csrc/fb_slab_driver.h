@@ -7,13 +7,19 @@
 // frozen columns' derivative fields cross the links once, at priming, and their tendency is never sent (it is masked,
 // SURVEY note N1).  No reference counterpart: the reference is single-process (main.cpp:259-323 is what one step computes).
 //
-// Schedule of one stage, compute stream S and communication stream C (events in between):
+// Schedule of one stage, compute stream S and communication stream C (events in between).  Small slabs (one active column group):
 //   S: backward strided x sub-pass of field group 0 | group 1 | ...            C: all-to-all(group 0) | all-to-all(group 1) ...
 //   S: row pass of row chunk 0 | chunk 1 | ...                                  C: all-to-all(tendency chunk 0) | chunk 1 ...
 //   S: forward x pass + RK update + derivatives (needs every row)
-// so the links are busy from the end of the first sub-pass to the arrival of the last tendency chunk, and only the
-// forward pass, the first sub-pass and the first row chunk are exposed.  The granularity follows the local work a piece hides
-// (fb_slab_plan): a piece that hides less than a collective's latency is not cut off.
+// so the links are busy from the end of the first sub-pass to the arrival of the last tendency chunk, and the forward pass, the
+// first sub-pass and the first row chunk are exposed.  Large slabs (BASELINE configs 4 and 5): the active columns of a rank are
+// cut into TWO column groups A, B with exchange buffers of their own (fb_ctx::grp), and the stage runs
+//   S: row chunk 0 | 1 | ...     | x pass(A): forward, update, derivatives, backward | x pass(B)            | row chunk 0 ...
+//   C:     a2a T_A(0), T_B(0) | ...  T_A(last) | T_B(last)                 | a2a W4_A                | a2a W4_B |
+// x pass(A) starts when A's tendency is in (B's is still on the links) and A's four derivative fields leave while B is
+// computed: between the last tendency chunk and the first derivative message the links never wait for a kernel, and only the
+// first row chunk is exposed.  The granularity follows the local work a piece hides (fb_slab_plan, slab_active_groups): a
+// piece that hides less than a collective's latency is not cut off.
 #pragma once
 #include "fb_transport.h"
 
@@ -23,8 +29,9 @@ struct fb_slab {
     fb_transport tp;
     bool connected, owns_streams;
     hipStream_t comp, comm;
-    hipEvent_t ev_f[4], ev_r[8], ev_w4, ev_t, ev_rows_done, ev_fwd_done, ev_misc[2];
+    hipEvent_t ev_f[4], ev_r[8], ev_w4, ev_t, ev_tg[2], ev_rows_done, ev_fwd_done, ev_misc[2];
     int nfg, nch;               // field groups of the derivative exchange (1, 2 or 4), row chunks of the tendency exchange (1..8)
+    int ncg;                    // active column groups (fb_ctx::nact): 2 = the stage is pipelined by column groups, and nfg == 1
     int step_ops;               // exchange operations issued per RK stage (diagnostics)
 };
 
@@ -33,8 +40,9 @@ struct fb_slab {
 #define FB_OP_XCHG_W4   2       /* arg = field group */
 #define FB_OP_ROW       3       /* arg = row chunk   */
 #define FB_OP_XCHG_T    4       /* arg = row chunk   */
-#define FB_OP_COL_FWD   5
-static void slab_plan(int nx, int ny, int world, int *nfg, int *nch)
+#define FB_OP_COL_FWD   5       /* arg = column group (0 unless the stage is pipelined by column groups) */
+#define FB_OP_COL_ALL_BWD 6     /* backward x sub-pass of all four fields of column group arg */
+static void slab_plan(int nx, int ny, int world, int *nfg, int *nch, int *ncg = nullptr)
 {
     const int dxw = (int)ceil(((double)(float)nx) / 3.0), dyw = (int)ceil(((double)(float)ny) / 3.0);
     int jmax, KA, KF;
@@ -50,18 +58,26 @@ static void slab_plan(int nx, int ny, int world, int *nfg, int *nch)
     if (const char *e = getenv("FB_SLAB_FIELD_GROUPS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) fg = v; }
     if (const char *e = getenv("FB_SLAB_ROW_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 8) ch = v; }
     while (ch > 1 && ((XL / ch) & 1 || XL % ch)) ch >>= 1;          // chunks are whole row pairs
+    const int cg = slab_active_groups(nx, world, KA);
+    if (cg > 1) fg = 1;                                             // pipelined by column groups instead: a group's four fields leave together
     *nfg = fg; *nch = ch;
+    if (ncg) *ncg = cg;
 }
 
 extern "C" int fb_slab_plan(int nx, int ny, int world, int *field_groups, int *row_chunks, int *ops, int cap)
 {
     if (!fb_size_supported(nx, ny) || world < 1 || !is_pow2(world) || nx / world < 2) { fail(FB_EINVAL, "fb_slab_plan: bad geometry"); return 0; }
-    int nfg, nch;
-    slab_plan(nx, ny, world, &nfg, &nch);
+    int nfg, nch, ncg;
+    slab_plan(nx, ny, world, &nfg, &nch, &ncg);
     if (field_groups) *field_groups = nfg;
     if (row_chunks) *row_chunks = nch;
     int n = 0;
     auto put = [&](int op, int arg) { if (ops && n < cap) ops[n] = op * 16 + arg; ++n; };
+    if (ncg > 1) {                                         // pipelined by column groups (arguments of kinds 2 and 5/6: the column group)
+        for (int h = 0; h < nch; ++h) { put(FB_OP_ROW, h); put(FB_OP_XCHG_T, h); }
+        for (int g = 0; g < ncg; ++g) { put(FB_OP_COL_FWD, g); put(FB_OP_COL_ALL_BWD, g); put(FB_OP_XCHG_W4, g); }
+        return n;
+    }
     for (int g = 0; g < nfg; ++g) { put(FB_OP_COL_BWD, g); if (world > 1) put(FB_OP_XCHG_W4, g); }
     for (int h = 0; h < nch; ++h) { put(FB_OP_ROW, h); if (world > 1) put(FB_OP_XCHG_T, h); }
     put(FB_OP_COL_FWD, 0);
@@ -80,6 +96,20 @@ extern "C" int fb_slab_geometry(int nx, int ny, int world, int *rows_local, int 
     return FB_OK;
 }
 
+// host logic, no GPU needed: how a rank's KA active columns are cut into column groups (1 or 2; whole 16-column tiles, the first
+// group takes the odd one).  Rank r's active slab is the global columns [r*KA, (r+1)*KA): group 0 its first cols2[0], group 1 the rest.
+extern "C" int fb_slab_col_groups(int nx, int ny, int world, int *ngroups, int *cols2)
+{
+    if (!fb_size_supported(nx, ny) || world < 1 || !is_pow2(world) || nx / world < 2) return fail(FB_EINVAL, "fb_slab_col_groups: bad geometry");
+    const int dxw = (int)ceil(((double)(float)nx) / 3.0), dyw = (int)ceil(((double)(float)ny) / 3.0);
+    int jmax, KA, KF;
+    slab_split(ny, (double)(float)((double)dxw * dxw + (double)dyw * dyw), world, jmax, KA, KF);
+    const int na = world == 1 ? 1 : slab_active_groups(nx, world, KA), tiles = KA / 16;
+    if (ngroups) *ngroups = na;
+    if (cols2) for (int g = 0; g < 2; ++g) cols2[g] = g < na ? 16 * (tiles / na + (g < tiles % na ? 1 : 0)) : 0;
+    return FB_OK;
+}
+
 // ---- creation ----
 extern "C" int fb_slab_destroy(fb_slab *s)
 {
@@ -89,7 +119,7 @@ extern "C" int fb_slab_destroy(fb_slab *s)
     if (s->connected && s->tp.destroy) s->tp.destroy(s->tp.self);
     if (s->m) fb_model_destroy(s->m);
     if (s->c) fb_destroy(s->c);
-    hipEvent_t *evs[] = {&s->ev_w4, &s->ev_t, &s->ev_rows_done, &s->ev_fwd_done, &s->ev_misc[0], &s->ev_misc[1]};
+    hipEvent_t *evs[] = {&s->ev_w4, &s->ev_t, &s->ev_tg[0], &s->ev_tg[1], &s->ev_rows_done, &s->ev_fwd_done, &s->ev_misc[0], &s->ev_misc[1]};
     for (hipEvent_t *e : evs) if (*e) hipEventDestroy(*e);
     for (auto &e : s->ev_f) if (e) hipEventDestroy(e);
     for (auto &e : s->ev_r) if (e) hipEventDestroy(e);
@@ -111,16 +141,18 @@ extern "C" int fb_slab_create(fb_slab **out, int nx, int ny, float lx, float ly,
         return bail(fail(FB_EHIP, "fb_slab_create: cannot create streams"));
     s->owns_streams = true;
     s->c->stream = s->comp;
-    hipEvent_t *evs[] = {&s->ev_w4, &s->ev_t, &s->ev_rows_done, &s->ev_fwd_done, &s->ev_misc[0], &s->ev_misc[1], &s->ev_f[0], &s->ev_f[1], &s->ev_f[2],
+    hipEvent_t *evs[] = {&s->ev_w4, &s->ev_t, &s->ev_tg[0], &s->ev_tg[1], &s->ev_rows_done, &s->ev_fwd_done, &s->ev_misc[0], &s->ev_misc[1], &s->ev_f[0], &s->ev_f[1], &s->ev_f[2],
                          &s->ev_f[3], &s->ev_r[0], &s->ev_r[1], &s->ev_r[2], &s->ev_r[3], &s->ev_r[4], &s->ev_r[5], &s->ev_r[6], &s->ev_r[7]};
     for (hipEvent_t *e : evs)
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(FB_EHIP, "fb_slab_create: cannot create events"));
     if ((rc = model_create_impl(&s->m, s->c, nu, dt, true))) return bail(rc);
     slab_plan(nx, ny, world, &s->nfg, &s->nch);
+    s->ncg = s->c->nact;
+    if (s->ncg > 1) s->nfg = 1;
     // Nothing to overlap when a stage has one field group and one row chunk (small slabs): the exchanges then go on the compute
     // stream, in order, and the stage has no cross-stream hand-overs (each costs the GPU ~10-15 us of idling; tools/slab_local_time.py:
     // rank-local 4096^2 step on 8 ranks 0.47 -> 0.3x ms).  FB_SLAB_TWO_STREAMS=1 keeps the separate communication stream.
-    if (s->nfg == 1 && s->nch == 1 && !getenv("FB_SLAB_TWO_STREAMS")) {
+    if (s->nfg == 1 && s->nch == 1 && s->ncg == 1 && !getenv("FB_SLAB_TWO_STREAMS")) {
         hipStreamDestroy(s->comm);
         s->comm = s->comp;
     }
@@ -159,10 +191,10 @@ extern "C" int fb_slab_info(fb_slab *s, int *rows_local, int *cols_active, int *
     if (!s) return fail(FB_EINVAL, "slab NULL");
     const fb_ctx *c = s->c;
     if (rows_local) *rows_local = c->XL;
-    if (cols_active) *cols_active = c->grp[0].ncols;
-    if (cols_frozen) *cols_frozen = c->ngroups > 1 ? c->grp[1].ncols : 0;
+    if (cols_active) *cols_active = c->world > 1 ? c->KA : c->grp[0].ncols;        // every active column group together
+    if (cols_frozen) *cols_frozen = c->ngroups > c->nact ? c->grp[c->nact].ncols : 0;
     if (ky0_active) *ky0_active = c->grp[0].ky0;
-    if (ky0_frozen) *ky0_frozen = c->ngroups > 1 ? c->grp[1].ky0 : 0;
+    if (ky0_frozen) *ky0_frozen = c->ngroups > c->nact ? c->grp[c->nact].ky0 : 0;
     if (field_groups) *field_groups = s->nfg;
     if (row_chunks) *row_chunks = s->nch;
     return FB_OK;
@@ -235,7 +267,8 @@ extern "C" int fb_slab_set_vort_local(fb_slab *s, const float *d_rows)
     // readField + fftwf_execute(p_fwd_vort), main.cpp:143-144,256: y transform of the local rows -> transpose -> x transform of the local columns
     RowArgs a = row_args_base(c);
     a.rin = d_rows;
-    a.T = c->world == 1 ? view_single(c, m->gb[0].t_send, 0) : view_slab(c, m->gb[0].t_send, m->gb[1].t_send, 1);
+    const cf *ts[3] = {m->gb[0].t_send, m->gb[1].t_send, m->gb[2].t_send};
+    a.T = c->world == 1 ? view_single(c, m->gb[0].t_send, 0) : view_slab(c, ts, 1);
     if ((rc = launch_row<ROW_FWD>(c, a))) return rc;
     if ((rc = slab_after(s->comm, s->comp, s->ev_misc[0]))) return rc;
     for (int g = 0; g < c->ngroups; ++g) {
@@ -283,7 +316,8 @@ static int slab_c2r_of_state(fb_slab *s, int what, float scale, float *d_rows)
     }
     if ((rc = slab_after(s->comp, s->comm, s->ev_misc[1]))) return rc;
     RowArgs a = row_args_base(c);
-    a.M = c->world == 1 ? view_single(c, m->gb[0].t_send, 0) : view_slab(c, m->gb[0].t_send, m->gb[1].t_send, 1);
+    const cf *ts[3] = {m->gb[0].t_send, m->gb[1].t_send, m->gb[2].t_send};
+    a.M = c->world == 1 ? view_single(c, m->gb[0].t_send, 0) : view_slab(c, ts, 1);
     a.rout = d_rows; a.scale = scale;
     return launch_row<ROW_INV>(c, a);
 }
@@ -313,18 +347,65 @@ static int slab_prime(fb_slab *s)
     fb_ctx *c = s->c; fb_model *m = s->m;
     int rc;
     if ((rc = model_prime(m))) return rc;                   // derivatives of every column; backward x pass finished on the frozen tiles
-    if (c->ngroups > 1) {                                   // the frozen columns' four fields cross the links once and stay in w4_recv
-        const size_t blk = 4 * (size_t)c->XL * c->grp[1].ncols;
+    if (c->ngroups > c->nact) {                             // the frozen columns' four fields cross the links once and stay in w4_recv
+        const int gf = c->nact;
+        const size_t blk = 4 * (size_t)c->XL * c->grp[gf].ncols;
         if ((rc = slab_after(s->comm, s->comp, s->ev_misc[0]))) return rc;
-        if ((rc = slab_xchg(s, m->gb[1].w4_send, m->gb[1].w4_recv, blk, 0, blk))) return rc;
+        if ((rc = slab_xchg(s, m->gb[gf].w4_send, m->gb[gf].w4_recv, blk, 0, blk))) return rc;
         if ((rc = slab_after(s->comp, s->comm, s->ev_misc[1]))) return rc;
     }
     return FB_OK;
 }
 
+// Pipelined by column groups (ncg == 2).  On entry the derivative fields of every group are complete in w4_recv (m->primed == 2:
+// slab_groups_prologue after priming, or the previous stage).
+static int slab_stage_groups(fb_slab *s, int stage)
+{
+    fb_ctx *c = s->c; fb_model *m = s->m;
+    int rc;
+    const int rows = c->XL / s->nch;
+    // row pass (main.cpp:154-237, y part) in row chunks; each chunk's tendency rows leave, group by group, while the next chunk is computed
+    for (int h = 0; h < s->nch; ++h) {
+        if ((rc = launch_row<ROW_FUSED>(c, fused_row_args(m, h * rows, rows)))) return rc;
+        if ((rc = slab_after(s->comm, s->comp, s->ev_r[h]))) return rc;
+        for (int g = 0; g < s->ncg; ++g) {
+            const size_t nc = c->grp[g].ncols, fld = (size_t)c->XL * nc;
+            if ((rc = slab_xchg(s, m->gb[g].t_send, m->gb[g].t_recv, fld, (size_t)h * rows * nc, (size_t)rows * nc))) return rc;
+            if (h == s->nch - 1) HIPCHK(hipEventRecord(s->ev_tg[g], s->comm));         // group g's tendency is complete
+        }
+    }
+    // per column group: forward x pass, viscosity, mask, RK stage update, derivatives of the new stage state, backward x pass
+    // (main.cpp:148,179-212,237-251,296-312); the group's four fields leave while the next group is computed
+    for (int g = 0; g < s->ncg; ++g) {
+        const size_t fld = (size_t)c->XL * c->grp[g].ncols;
+        HIPCHK(hipStreamWaitEvent(s->comp, s->ev_tg[g], 0));
+        if ((rc = model_col_fwd(m, stage, g))) return rc;
+        if ((rc = model_col_bwd_active(m, 0, 4, g))) return rc;
+        if ((rc = slab_after(s->comm, s->comp, s->ev_f[g]))) return rc;
+        if ((rc = slab_xchg(s, m->gb[g].w4_send, m->gb[g].w4_recv, 4 * fld, 0, 4 * fld))) return rc;
+    }
+    m->primed = 2;
+    return slab_after(s->comp, s->comm, s->ev_w4);          // the next row pass (or a record pass) reads w4_recv
+}
+// after priming: backward x pass on the active tiles of every group and the first exchange of the derivative fields
+static int slab_groups_prologue(fb_slab *s)
+{
+    fb_ctx *c = s->c; fb_model *m = s->m;
+    int rc;
+    for (int g = 0; g < s->ncg; ++g) {
+        const size_t fld = (size_t)c->XL * c->grp[g].ncols;
+        if ((rc = model_col_bwd_active(m, 0, 4, g))) return rc;
+        if ((rc = slab_after(s->comm, s->comp, s->ev_f[g]))) return rc;
+        if ((rc = slab_xchg(s, m->gb[g].w4_send, m->gb[g].w4_recv, 4 * fld, 0, 4 * fld))) return rc;
+    }
+    m->primed = 2;
+    return slab_after(s->comp, s->comm, s->ev_w4);
+}
+
 static int slab_stage(fb_slab *s, int stage)
 {
     fb_ctx *c = s->c; fb_model *m = s->m;
+    if (s->ncg > 1) return slab_stage_groups(s, stage);
     GroupBufs &B = m->gb[0];
     const size_t fld = (size_t)c->XL * c->grp[0].ncols;     // one field's block for one peer
     int rc;
@@ -370,6 +451,7 @@ extern "C" int fb_slab_step(fb_slab *s, int nsteps)
         HIPCHK(hipEventRecord(s->ev_rows_done, s->comp));
         HIPCHK(hipEventRecord(s->ev_fwd_done, s->comp));
     }
+    if (s->ncg > 1 && s->m->primed == 1 && (rc = slab_groups_prologue(s))) return rc;
     for (int n = 0; n < nsteps; ++n)
         for (int k = 0; k < 4; ++k)                         // main.cpp:288-317
             if ((rc = slab_stage(s, k))) return rc;

@@ -68,10 +68,12 @@ extern "C" int fb_size_supported(int nx, int ny) { return size_ok(nx) && size_ok
 // --------------------------------------------------------------------------------------------
 // context
 // --------------------------------------------------------------------------------------------
-// A set of local ky columns with a pitch of its own.  One GPU: one group holding every column.  Multi-GPU: group 0 =
-// this rank's slab of the ACTIVE columns (ky < world*KA: at least one mode inside the dealiasing circle, exchanged every
-// RK stage), group 1 = its slab of the FROZEN columns beyond them (SURVEY note N1: their state never changes, so their
-// derivative fields cross the links once, at priming).
+// A set of local ky columns with a pitch of its own.  One GPU: one group holding every column.  Multi-GPU: groups
+// 0 .. nact-1 = this rank's slabs of the ACTIVE columns (ky < world*KA: at least one mode inside the dealiasing circle, exchanged
+// every RK stage; two groups where the stage is pipelined by column groups -- fb_slab_driver.h -- else one), the last group =
+// its slab of the FROZEN columns beyond them (SURVEY note N1: their state never changes, so their derivative fields cross the
+// links once, at priming).  A rank's active slab [rank*KA, (rank+1)*KA) is cut locally: group 0 holds its first columns, group 1
+// the rest, so which rank owns which ky column does not depend on the cut.
 struct ColGroup {
     int ncols;                  // local columns == pitch of every array of the group (multiple of 16)
     int ky0;                    // global ky of local column 0
@@ -81,8 +83,8 @@ struct ColGroup {
 struct fb_ctx {
     int world, rank;            // slab decomposition: this process owns x rows [rank*XL, (rank+1)*XL)
     int XL;
-    int ngroups; ColGroup grp[2];
-    int KA, KF, katot;          // world > 1: columns per rank of the active / frozen slabs, katot = world*KA
+    int ngroups, nact; ColGroup grp[3];   // nact active groups (1 or 2), then the frozen one if KF > 0
+    int KA, KF, katot;          // world > 1: columns per rank of the active (all groups together) / frozen slabs, katot = world*KA
     int nx, ny, hy, P;          // P = grp[0].ncols: pitch of the private layouts on one GPU
     int N1, N2;                 // nx = N1*N2
     float lx, ly;
@@ -231,6 +233,21 @@ static void slab_split(int ny, double gws, int world, int &jmax, int &KA, int &K
     KF = nf > 0 ? round16((nf + world - 1) / world) : 0;
 }
 
+// How many column groups the ACTIVE columns of a rank are cut into (fb_slab_driver.h: with two, a stage's forward x pass,
+// update and backward x pass start on the first group while the second group's tendency is still on the links, and the first
+// group's derivative fields leave while the second group is computed).  Worth it where one group's column work hides a
+// collective's latency several times over: ~17.5 passes over nx*KA complex at ~5 TB/s.  FB_SLAB_COL_GROUPS=1|2 overrides.
+static int slab_active_groups(int nx, int world, int KA)
+{
+    int na = 1;
+    if (world > 1 && KA >= 32) {
+        const double col_us = 17.5 * (double)nx * KA * 8.0 / 5e6;
+        if (col_us >= 100.0) na = 2;
+        if (const char *e = getenv("FB_SLAB_COL_GROUPS")) { const int v = atoi(e); if (v == 1 || v == 2) na = v; }
+    }
+    return na;
+}
+
 extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, int rank, int world)
 {
     if (!out) return fail(FB_EINVAL, "fb_create: out is NULL");
@@ -261,15 +278,22 @@ extern "C" int fb_create_slab(fb_ctx **out, int nx, int ny, float lx, float ly, 
     if (world == 1) {
         c->P = round16(c->hy);
         if (const char *e = getenv("FB_PITCH_EXTRA")) c->P += 16 * atoi(e);   // tuning hook (disables the autotuner below)
-        c->ngroups = 1; c->grp[0] = ColGroup{c->P, 0, 0};
+        c->ngroups = c->nact = 1; c->grp[0] = ColGroup{c->P, 0, 0};
         c->KA = c->P; c->KF = 0; c->katot = c->P;
         Ptot = c->P + 96;                                  // room for the pitch candidates of autotune_pitch()
     } else {
         c->katot = world * c->KA;
-        c->ngroups = c->KF > 0 ? 2 : 1;
-        c->grp[0] = ColGroup{c->KA, rank * c->KA, 0};
-        c->grp[1] = ColGroup{c->KF, c->katot + rank * c->KF, 0};
-        c->P = c->KA;
+        c->nact = slab_active_groups(nx, world, c->KA);
+        c->ngroups = c->nact + (c->KF > 0 ? 1 : 0);
+        const int tiles = c->KA / 16;
+        int off = 0;
+        for (int g = 0; g < c->nact; ++g) {                // whole 16-column tiles, the first group takes the odd one
+            const int nc = 16 * (tiles / c->nact + (g < tiles % c->nact ? 1 : 0));
+            c->grp[g] = ColGroup{nc, rank * c->KA + off, 0};
+            off += nc;
+        }
+        if (c->KF > 0) c->grp[c->nact] = ColGroup{c->KF, c->katot + rank * c->KF, 0};
+        c->P = c->grp[0].ncols;
         Ptot = c->katot + world * c->KF + 16;
     }
     c->h_gx.assign(nx, 0.f); c->h_kx2.assign(nx, 0.0); c->h_gy.assign(Ptot, 0.f); c->h_ky2.assign(Ptot, 0.0);
@@ -839,20 +863,22 @@ static unsigned magic_div(int d) { return d > 0 ? (unsigned)((1ull << 32) / (uns
 static RowView view_single(const fb_ctx *c, const cf *base, long fstride)
 {
     RowView v; memset(&v, 0, sizeof(v));
-    v.a = v.f = base; v.fstrA = v.fstrF = fstride; v.ka = c->P; v.kf = 16; v.katot = 0x7fffffff;
+    v.a = v.b = v.f = base; v.fstrA = v.fstrB = v.fstrF = fstride; v.ka = v.ka0 = c->P; v.kb = 0; v.kf = 16; v.katot = 0x7fffffff;
     return v;
 }
-// multi-GPU exchange buffers [peer][nfields][XL][KA] (active columns) and [peer][nfields][XL][KF] (frozen columns)
-static RowView view_slab(const fb_ctx *c, const cf *act, const cf *frz, int nfields)
+// multi-GPU exchange buffers, one per column group: [peer][nfields][XL][ncols_g]; bufs[g] = group g's (fb_ctx::grp order)
+static RowView view_slab(const fb_ctx *c, const cf *const *bufs, int nfields)
 {
     RowView v; memset(&v, 0, sizeof(v));
-    v.a = act; v.f = frz ? frz : act; v.ka = c->KA; v.kf = c->KF > 0 ? c->KF : 16; v.katot = c->katot;
-    v.fstrA = (long)c->XL * v.ka; v.fstrF = (long)c->XL * v.kf;
-    v.sstrA = (long)nfields * v.fstrA; v.sstrF = (long)nfields * v.fstrF;
+    v.a = bufs[0]; v.b = c->nact > 1 ? bufs[1] : bufs[0]; v.f = c->KF > 0 ? bufs[c->nact] : bufs[0];
+    v.ka = c->KA; v.ka0 = c->grp[0].ncols; v.kb = c->nact > 1 ? c->grp[1].ncols : 0; v.kf = c->KF > 0 ? c->KF : 16;
+    v.katot = c->katot;
+    v.fstrA = (long)c->XL * v.ka0; v.fstrB = (long)c->XL * v.kb; v.fstrF = (long)c->XL * v.kf;
+    v.sstrA = (long)nfields * v.fstrA; v.sstrB = (long)nfields * v.fstrB; v.sstrF = (long)nfields * v.fstrF;
     v.magA = magic_div(v.ka); v.magF = magic_div(v.kf);
     return v;
 }
-
+// the row-side view of one kind of exchange buffer of the model (which: 0 w4_recv, 1 t_send)
 static RowArgs row_args_base(const fb_ctx *c)
 {
     RowArgs a; memset(&a, 0, sizeof(a));
@@ -938,7 +964,7 @@ struct GroupBufs { cf *ZA, *ZB, *ACC, *w4_send, *w4_recv, *t_send, *t_recv; };
 struct fb_model {
     fb_ctx *c;
     float nu, dt;
-    GroupBufs gb[2];
+    GroupBufs gb[3];
     bool phase_flow;                 // driven phase by phase (fb_slab_*): always the three-kernel column path
     // single-pass x-transform path (fb_col_full.h): ZA/ZB/ACC then use that kernel's private layout; nsub = nx/4096
     // (2: the remaining radix-2 step of the x transform is fused into the row pass, k_rowh2)
@@ -988,7 +1014,7 @@ static int model_create_impl(fb_model **out, fb_ctx *c, float nu, float dt, bool
         const size_t n = grp_elems(c, c->grp[g]);
         GroupBufs &B = m->gb[g];
         alloc0(&B.ZA, n);
-        if (g == 0) { alloc0(&B.ZB, n); alloc0(&B.ACC, n); }     // the frozen group's state never changes: vort_c only
+        if (g < c->nact) { alloc0(&B.ZB, n); alloc0(&B.ACC, n); }     // the frozen group's state never changes: vort_c only
         alloc0(&B.w4_send, 4 * n); alloc0(&B.t_send, n);
         if (c->world > 1) { alloc0(&B.w4_recv, 4 * n); alloc0(&B.t_recv, n); }
         else { B.w4_recv = B.w4_send; B.t_recv = B.t_send; }
@@ -1029,7 +1055,7 @@ extern "C" int fb_model_info(fb_model *m, size_t *hbm, size_t *alg)
     const fb_ctx *c = m->c;
     if (hbm) {
         size_t n = m->src ? (size_t)c->XL * c->ny * 4 : 0;
-        for (int g = 0; g < c->ngroups; ++g) n += (c->world > 1 ? (g == 0 ? 13 : 11) : 8) * grp_elems(c, c->grp[g]) * sizeof(cf);
+        for (int g = 0; g < c->ngroups; ++g) n += (c->world > 1 ? (g < c->nact ? 13 : 11) : 8) * grp_elems(c, c->grp[g]) * sizeof(cf);
         *hbm = n;
     }
     if (alg) *alg = (size_t)320 * c->nx * c->ny;
@@ -1169,29 +1195,32 @@ static int model_prime(fb_model *m)
 }
 // backward strided sub-pass on the active tiles, fields [f0, f1): the multi-GPU step pipelines it field by field against
 // the exchange; the fused flow runs it once right after priming (its stage loop starts with the row pass)
-static int model_col_bwd_active(fb_model *m, int f0 = 0, int f1 = 4)
+static int model_col_bwd_active(fb_model *m, int f0 = 0, int f1 = 4, int g = 0)
 {
     fb_ctx *c = m->c;
-    const ColGroup &G = c->grp[0];
-    return launch_col_strided<+1>(c, G, m->gb[0].w4_send + (size_t)f0 * w4_fstride(c, G), f1 - f0, w4_fstride(c, G), rowmap_w4(c, G), 0, G.nct_active);
+    const ColGroup &G = c->grp[g];
+    return launch_col_strided<+1>(c, G, m->gb[g].w4_send + (size_t)f0 * w4_fstride(c, G), f1 - f0, w4_fstride(c, G), rowmap_w4(c, G), 0, G.nct_active);
 }
 static RowArgs fused_row_args(fb_model *m, int x0, int nrows)
 {
     fb_ctx *c = m->c;
     RowArgs a = row_args_base(c);
     if (c->world == 1) { a.M = view_single(c, m->gb[0].w4_recv, (long)priv_elems(c)); a.T = view_single(c, m->gb[0].t_send, 0); }
-    else { a.M = view_slab(c, m->gb[0].w4_recv, m->gb[1].w4_recv, 4); a.T = view_slab(c, m->gb[0].t_send, m->gb[1].t_send, 1); a.t_frozen = 0; }
+    else {
+        const cf *w4[3] = {m->gb[0].w4_recv, m->gb[1].w4_recv, m->gb[2].w4_recv}, *ts[3] = {m->gb[0].t_send, m->gb[1].t_send, m->gb[2].t_send};
+        a.M = view_slab(c, w4, 4); a.T = view_slab(c, ts, 1); a.t_frozen = 0;
+    }
     a.src = m->src; a.src_nz = m->src_nz; a.scale = 1.0f / (float)((size_t)c->nx * c->ny); a.x0 = x0; a.nx = nrows; a.prescaled = m->prescale ? 1 : 0;
     return a;
 }
 // forward x pass of the tendency + RK stage update + derivatives of the new stage state (three-kernel path)
-static int model_col_fwd(fb_model *m, int stage)
+static int model_col_fwd(fb_model *m, int stage, int g = 0)
 {
     fb_ctx *c = m->c;
     int rc;
-    if ((rc = launch_col_strided<-1>(c, c->grp[0], m->gb[0].t_recv, 1, 0, rowmap_natural(), 0, c->grp[0].nct_active))) return rc;
+    if ((rc = launch_col_strided<-1>(c, c->grp[g], m->gb[g].t_recv, 1, 0, rowmap_natural(), 0, c->grp[g].nct_active))) return rc;
     m->primed = 1;
-    return launch_col_mid(c, mid_args(m, 0, stage));
+    return launch_col_mid(c, mid_args(m, g, stage));
 }
 
 // optional per-launch HIP-event profiler (bench.py's roofline leg)

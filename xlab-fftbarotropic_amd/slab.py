@@ -21,7 +21,7 @@ import math
 
 import numpy as np
 
-OP_COL_BWD, OP_XCHG_W4, OP_ROW, OP_XCHG_T, OP_COL_FWD = 1, 2, 3, 4, 5
+OP_COL_BWD, OP_XCHG_W4, OP_ROW, OP_XCHG_T, OP_COL_FWD, OP_COL_ALL_BWD = 1, 2, 3, 4, 5, 6
 
 
 def _round16(v):
@@ -43,6 +43,22 @@ def slab_geometry(nx, ny, world):
     return nx // world, ka, kf
 
 
+def slab_col_groups(nx, ny, world):
+    """Columns per rank of the active column groups (one, or two where a stage is pipelined by column groups) -- mirrors
+    slab_active_groups() / fb_slab_col_groups in the engine.  A rank's active slab [rank*KA, (rank+1)*KA) is cut locally: its
+    first n_0 columns are group 0, the rest group 1."""
+    import os
+    _, ka, _ = slab_geometry(nx, ny, world)
+    na = 1
+    if world > 1 and ka >= 32:
+        if 17.5 * nx * ka * 8.0 / 5e6 >= 100.0:              # one rank's column work of a stage, microseconds at ~5 TB/s
+            na = 2
+        if os.environ.get("FB_SLAB_COL_GROUPS") in ("1", "2"):
+            na = int(os.environ["FB_SLAB_COL_GROUPS"])
+    tiles = ka // 16
+    return [16 * (tiles // na + (1 if g < tiles % na else 0)) for g in range(na)]
+
+
 def stage_plan(nx, ny, world):
     """(field groups, row chunks) of one RK stage's two transposes -- mirrors slab_plan() in csrc/fb_slab_driver.h."""
     xl, ka, _ = slab_geometry(nx, ny, world)
@@ -51,6 +67,8 @@ def stage_plan(nx, ny, world):
     ch = 1 if world == 1 else (2 if row_us >= 100.0 else 1)
     while ch > 1 and ((xl // ch) & 1 or xl % ch):
         ch >>= 1
+    if len(slab_col_groups(nx, ny, world)) > 1:
+        fg = 1                                               # pipelined by column groups: a group's four fields leave together
     return fg, ch
 
 
@@ -58,6 +76,13 @@ def stage_schedule(nx, ny, world):
     """Operations of one RK stage in issue order, as (kind, argument) -- mirrors fb_slab_plan."""
     fg, ch = stage_plan(nx, ny, world)
     ops = []
+    ncg = len(slab_col_groups(nx, ny, world))
+    if ncg > 1:                                              # arguments of OP_XCHG_W4 / OP_COL_*: the column group
+        for h in range(ch):
+            ops += [(OP_ROW, h), (OP_XCHG_T, h)]
+        for g in range(ncg):
+            ops += [(OP_COL_FWD, g), (OP_COL_ALL_BWD, g), (OP_XCHG_W4, g)]
+        return ops
     for g in range(fg):
         ops.append((OP_COL_BWD, g))
         if world > 1:
@@ -321,7 +346,10 @@ class SlabModel:
         self.XL, self.KA, self.KF = slab_geometry(nx, ny, world)
         assert (self.be.XL, self.be.KA, self.be.KF) == (self.XL, self.KA, self.KF)
         self.field_groups, self.row_chunks = stage_plan(nx, ny, world)
-        self.primed = False
+        self.cols = slab_col_groups(nx, ny, world) + ([self.KF] if self.KF else [])     # columns per rank of every group, the engine's order
+        self.nact = len(self.cols) - (1 if self.KF else 0)
+        assert list(self.be.ncols) == self.cols
+        self.primed = 0
 
     def _xchg(self, recv, send, stride, offset, count):
         if self.world > 1:
@@ -331,12 +359,11 @@ class SlabModel:
     def set_vort_local(self, vort_rows):
         be = self.be
         assert tuple(vort_rows.shape) == (self.XL, self.ny)
-        be.r2c_rows(vort_rows)                                                    # -> t_send (active + frozen)
-        self._xchg(be.t_recv[0], be.t_send[0], self.XL * self.KA, 0, self.XL * self.KA)
-        if self.KF:
-            self._xchg(be.t_recv[1], be.t_send[1], self.XL * self.KF, 0, self.XL * self.KF)
+        be.r2c_rows(vort_rows)                                                    # -> t_send (every group)
+        for g, n in enumerate(self.cols):
+            self._xchg(be.t_recv[g], be.t_send[g], self.XL * n, 0, self.XL * n)
         be.r2c_cols()
-        self.primed = False
+        self.primed = 0
 
     def set_source_local(self, src_rows):
         self.be.set_source(src_rows)
@@ -344,36 +371,55 @@ class SlabModel:
     def vort_local(self):
         be = self.be
         be.c2r_cols()                                                             # -> t_recv, [dst][XL][ncols]
-        self._xchg(be.t_send[0], be.t_recv[0], self.XL * self.KA, 0, self.XL * self.KA)
-        if self.KF:
-            self._xchg(be.t_send[1], be.t_recv[1], self.XL * self.KF, 0, self.XL * self.KF)
+        for g, n in enumerate(self.cols):
+            self._xchg(be.t_send[g], be.t_recv[g], self.XL * n, 0, self.XL * n)
         return be.c2r_rows()
 
     def step(self, n=1):
         be = self.be
         if n <= 0:
             return
-        fld = self.XL * self.KA
         if not self.primed:
             be.prime()                                                            # derivatives of every column; frozen ones final
             if self.KF:
-                self._xchg(be.w4_recv[1], be.w4_send[1], 4 * self.XL * self.KF, 0, 4 * self.XL * self.KF)
-            self.primed = True
+                gf = self.nact
+                self._xchg(be.w4_recv[gf], be.w4_send[gf], 4 * self.XL * self.KF, 0, 4 * self.XL * self.KF)
+            self.primed = 1
+        if self.nact > 1 and self.primed == 1:                                    # slab_groups_prologue
+            for g in range(self.nact):
+                be.col_bwd(0, 4, g)
+                self._xchg(be.w4_recv[g], be.w4_send[g], 4 * self.XL * self.cols[g], 0, 4 * self.XL * self.cols[g])
+            self.primed = 2
         rows = self.XL // self.row_chunks
         for _ in range(n):
             for k in range(4):                                                    # main.cpp:288-317
                 for kind, arg in stage_schedule(self.nx, self.ny, self.world):
+                    if self.nact > 1:                                             # pipelined by column groups: arg of the column operations = the group
+                        if kind == OP_ROW:
+                            be.row(arg * rows, rows)
+                        elif kind == OP_XCHG_T:
+                            for g in range(self.nact):
+                                nc = self.cols[g]
+                                self._xchg(be.t_recv[g], be.t_send[g], self.XL * nc, arg * rows * nc, rows * nc)
+                        elif kind == OP_COL_FWD:
+                            be.col_fwd(k, arg)
+                        elif kind == OP_COL_ALL_BWD:
+                            be.col_bwd(0, 4, arg)
+                        else:
+                            self._xchg(be.w4_recv[arg], be.w4_send[arg], 4 * self.XL * self.cols[arg], 0, 4 * self.XL * self.cols[arg])
+                        continue
+                    fld = self.XL * self.cols[0]
                     if kind == OP_COL_BWD:
-                        be.col_bwd(4 * arg // self.field_groups, 4 * (arg + 1) // self.field_groups)
+                        be.col_bwd(4 * arg // self.field_groups, 4 * (arg + 1) // self.field_groups, 0)
                     elif kind == OP_XCHG_W4:
                         f0, f1 = 4 * arg // self.field_groups, 4 * (arg + 1) // self.field_groups
                         self._xchg(be.w4_recv[0], be.w4_send[0], 4 * fld, f0 * fld, (f1 - f0) * fld)
                     elif kind == OP_ROW:
                         be.row(arg * rows, rows)
                     elif kind == OP_XCHG_T:
-                        self._xchg(be.t_recv[0], be.t_send[0], fld, arg * rows * self.KA, rows * self.KA)
+                        self._xchg(be.t_recv[0], be.t_send[0], fld, arg * rows * self.cols[0], rows * self.cols[0])
                     else:
-                        be.col_fwd(k)
+                        be.col_fwd(k, 0)
 
     def close(self):
         self.be.close()
