@@ -282,6 +282,8 @@ class Model:
         if isinstance(a, np.ndarray):
             a = t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
         assert a.is_cuda and a.dtype == t.float32 and a.is_contiguous() and tuple(a.shape) == (self.nx, self.ny)
+        # the engine reads the buffer on ITS stream: whatever torch still has queued for it (a fill, a copy) must have landed
+        t.cuda.current_stream().synchronize()
         return a
 
     def set_vort(self, vort): a = self._dev(vort); check(lib().fb_model_set_vort(self._h, _ptr(a))); self.fop.synchronize()

@@ -225,6 +225,8 @@ class EngineSlab:
         if isinstance(a, np.ndarray):
             a = t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
         assert a.is_cuda and a.dtype == t.float32 and a.is_contiguous() and tuple(a.shape) == (self.XL, self.ny)
+        # the engine reads the buffer on ITS streams: whatever torch still has queued for it (a fill, a copy) must have landed
+        t.cuda.current_stream().synchronize()
         return a
 
     def set_vort_local(self, rows):
