@@ -88,3 +88,27 @@ def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+
+
+def dft2_r2c_definition(f):
+    """FFTW's r2c convention by its DEFINITION, no FFT library involved: Y[i, j] = sum_{x, y} f[x, y] exp(-2 pi i (i x / nx + j y / ny)),
+    j = 0 .. ny/2, as two dense matrix products in float64 / complex128 (fftw3 manual, "What FFTW Really Computes")."""
+    nx, ny = f.shape
+    wx = np.exp(-2j * np.pi * np.outer(np.arange(nx), np.arange(nx)) / nx)
+    wy = np.exp(-2j * np.pi * np.outer(np.arange(ny), np.arange(ny // 2 + 1)) / ny)
+    return wx @ f.astype(np.float64) @ wy
+
+
+def dft2_c2r_definition(s, ny):
+    """FFTW's c2r_2d on a half spectrum s[nx, ny/2+1] that need NOT be Hermitian (SURVEY note N2), by definition: the complex inverse
+    DFT (unnormalised, sign +) along x for every ky column, then per x row the 1-D c2r along y -- the real signal whose half spectrum
+    is the row, the imaginary parts at j = 0 and j = ny/2 being ignored: out[y] = Re z0 + (-1)^y Re z_{ny/2} + 2 sum_{0<j<ny/2} Re(z_j e^{+2 pi i j y/ny})."""
+    nx = s.shape[0]
+    wx = np.exp(+2j * np.pi * np.outer(np.arange(nx), np.arange(nx)) / nx)
+    z = wx @ s.astype(np.complex128)                                              # [x][ky]
+    j = np.arange(1, ny // 2)
+    e = np.exp(+2j * np.pi * np.outer(j, np.arange(ny)) / ny)                       # [j][y]
+    out = 2.0 * (z[:, 1:ny // 2] @ e).real
+    out += z[:, :1].real
+    out += z[:, ny // 2:ny // 2 + 1].real * ((-1.0) ** np.arange(ny))[None, :]
+    return out

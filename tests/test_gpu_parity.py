@@ -126,6 +126,20 @@ def test_r2c_c2r_vs_oracle(X, O, R, torch, nx, ny):
     assert np.array_equal(_bits(ds.cpu().numpy()), _bits(s))      # input preserved
 
 
+@pytest.mark.parametrize("nx,ny", [(64, 64), (128, 256), (192, 64), (256, 128)])
+def test_r2c_c2r_vs_the_dft_definition(X, R, torch, nx, ny):
+    """The engine's 2-D transforms against FFTW's documented DEFINITION (dense DFT matrices in float64, tests/ref_numpy.py) -- no FFT
+    library on either side of the comparison: sign, normalisation, half-spectrum layout and the non-Hermitian c2r semantics (note N2)."""
+    fop = X.FftwfOperation(nx, ny, 6e5, 6e5)
+    rng = np.random.default_rng(11 * nx + ny)
+    f = rng.standard_normal((nx, ny)).astype(np.float32)
+    got = fop.r2c(torch.from_numpy(f).cuda()).cpu().numpy()
+    assert R.rel_l2(got.view(np.float32), R.dft2_r2c_definition(f).view(np.float64)) < 5e-7
+    s = _rand_spec(nx, ny, 6)
+    back = fop.c2r(torch.from_numpy(s).cuda()).cpu().numpy()
+    assert R.rel_l2(back, R.dft2_c2r_definition(s, ny)) < 5e-7
+
+
 def test_r2c_vs_numpy_fp64_large(X, R, torch):
     """8192^2 (config 4 grid): checked against numpy fp64 directly."""
     n = 8192

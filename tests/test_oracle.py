@@ -229,6 +229,20 @@ def test_r2c_c2r_vs_numpy(nx, ny):
     assert R.rel_l2(O.c2r(s, ny), want) < 4e-7
 
 
+@pytest.mark.parametrize("nx,ny", [(64, 64), (96, 128), (192, 64)])
+def test_r2c_c2r_vs_the_dft_definition(nx, ny):
+    """The 2-D transforms against FFTW's documented DEFINITION of r2c / c2r (dense DFT matrices in float64, tests/ref_numpy.py), not
+    against another FFT library: conventions (sign, no normalisation, half-spectrum layout) and the non-Hermitian c2r semantics of
+    SURVEY note N2 are pinned to the mathematics.  (FFTW itself is absent from the image: DESIGN.md section 2.)"""
+    rng = np.random.default_rng(7 * nx + ny)
+    f = rng.standard_normal((nx, ny)).astype(np.float32)
+    assert R.rel_l2(O.r2c(f).view(np.float32), R.dft2_r2c_definition(f).view(np.float64)) < 4e-7
+    s = _rand_spec(nx, ny, 5)                                    # imaginary parts at ky = 0 and ky = ny/2, no Hermitian symmetry in x
+    assert R.rel_l2(O.c2r(s, ny), R.dft2_c2r_definition(s, ny)) < 4e-7
+    # and numpy's irfft2 has the same semantics (the yardstick of the larger tests)
+    assert R.rel_l2(np.fft.irfft2(s.astype(np.complex128), s=(nx, ny)) * (nx * ny), R.dft2_c2r_definition(s, ny)) < 1e-12
+
+
 def test_c2r_does_not_modify_input():
     s = _rand_spec(64, 64, 9)
     keep = s.copy()
