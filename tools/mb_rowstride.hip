@@ -38,6 +38,31 @@ __global__ void __launch_bounds__(256) k_tiles(float2 *data, long fstride, int P
     }
 }
 
+// the same bytes per wave as 32 columns x 64 rows (256-byte row segments): would wider column tiles stream faster?
+__global__ void __launch_bounds__(256) k_tiles_wide(float2 *data, long fstride, int P, int nct2, long ntiles)
+{
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, cp = lane & 15, h = lane >> 5, c32 = lane & 31;
+    for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const int f = (int)(tile / (256L * nct2));
+        const int rem = (int)(tile - (long)f * 256 * nct2);
+        const int b = rem / nct2, ct = rem - b * nct2;                // b: 256 blocks of 64 contiguous rows
+        float2 *base = data + (size_t)f * fstride + (size_t)(b * 64) * P + ct * 32;
+        f4v in[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) in[m] = *reinterpret_cast<const f4v *>(base + (size_t)(g + 4 * m) * P + 2 * cp);
+        f4v acc = in[0];
+#pragma unroll
+        for (int m = 1; m < 16; ++m) acc += in[m];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int k = h + 2 * s;
+            f2v o = {acc.x + (float)k, acc.y};
+            *reinterpret_cast<f2v *>(base + (size_t)k * P + c32) = o;
+        }
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int nx = 16384, P = 8208, nct = 488;                      // active 16-column tiles at 16384^2
@@ -57,6 +82,18 @@ int main(int argc, char **argv)
             float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5;
             printf("grid %5d  rows %3d apart : %.3f ms per launch, %.0f GB/s\n", grid, S, ms, bytes / ms / 1e6);
         }
+    {
+        const int nct2 = nct / 2;
+        const long nt = 4L * 256 * nct2;
+        for (int grid : grids) {
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k_tiles_wide, dim3(grid), dim3(256), 0, 0, d, (long)n, P, nct2, nt);
+            (void)hipDeviceSynchronize(); (void)hipEventRecord(e0, 0);
+            for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_tiles_wide, dim3(grid), dim3(256), 0, 0, d, (long)n, P, nct2, nt);
+            (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+            printf("grid %5d  32 columns x 64 contiguous rows (256-byte segments) : %.3f ms per launch, %.0f GB/s\n", grid, ms, 2.0 * nt * 64 * 256 / ms / 1e6);
+        }
+    }
     CK(hipDeviceSynchronize());
     return 0;
 }
