@@ -181,7 +181,7 @@ def main():
         # the engine-driven model: local passes, exchange buffers and the RCCL all-to-all transposes behind the C ABI
         model = slab.SlabModel(n, n, dt=dt, rank=rank, world=world)
         slab_info = {"rows_per_rank": model.XL, "active_cols_per_rank": model.KA, "frozen_cols_per_rank": model.KF,
-                     "field_groups": model.field_groups, "row_chunks": model.row_chunks,
+                     "field_groups": model.field_groups, "row_chunks": model.row_chunks, "col_groups": model.col_groups,
                      "transport": model.transport}
         if args.backend == "nccl" and not model.transport.startswith("rccl (engine"):
             raise SystemExit("bench.py: the multi-GPU line is only printed for the engine's RCCL transport, got %r" % model.transport)

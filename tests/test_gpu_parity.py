@@ -454,6 +454,26 @@ def test_api_edge_cases(X, torch):
     assert L_.fb_create_slab(C.byref(h), 256, 256, 6e5, 6e5, 0, 3) == 1   # world not a power of two
     assert L_.fb_create(C.byref(h), 32, 32, 6e5, 6e5) == 5                # below the minimum size
     assert L_.fb_create(C.byref(h), 32768, 64, 6e5, 6e5) == 5             # above the maximum size
+    # round 3's entry points: the async copies and the slab's event hand-overs refuse NULLs instead of faulting, and do their job
+    assert L_.fb_memcpy_h2d_async(None, None, None, 16) == 1 and L_.fb_slab_record_event(None, None) == 1 and L_.fb_slab_wait_event(None, None) == 1
+    st, ev, hp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert L_.fb_stream_create(C.byref(st)) == 0 and L_.fb_event_create(C.byref(ev)) == 0 and L_.fb_malloc_host(C.byref(hp), 4 * n * n) == 0
+    src = (C.c_float * (n * n)).from_address(hp.value)
+    for i in range(n * n):
+        src[i] = float(i % 251)
+    dst = torch.zeros((n, n), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    assert L_.fb_memcpy_h2d_async(st, C.c_void_p(dst.data_ptr()), hp, 4 * n * n) == 0
+    assert L_.fb_event_record(ev, st) == 0 and L_.fb_event_synchronize(ev) == 0
+    assert np.array_equal(dst.cpu().numpy().ravel(), np.arange(n * n, dtype=np.float32) % 251)
+    one = C.c_void_p()
+    assert L_.fb_slab_create(C.byref(one), n, n, 6e5, 6e5, 6.5, 3.0, 0, 1) == 0            # world == 1: connected by construction
+    assert L_.fb_slab_wait_event(one, ev) == 0 and L_.fb_slab_record_event(one, ev) == 0 and L_.fb_event_synchronize(ev) == 0
+    assert L_.fb_slab_destroy(one) == 0
+    ng, cols = C.c_int(), (C.c_int * 2)()
+    assert L_.fb_slab_col_groups(8192, 8192, 4, C.byref(ng), cols) == 0 and (ng.value, cols[0], cols[1]) == (2, 496, 480)
+    assert L_.fb_slab_col_groups(1000, 1000, 4, C.byref(ng), cols) == 1
+    assert L_.fb_free_host(hp) == 0 and L_.fb_event_destroy(ev) == 0 and L_.fb_stream_destroy(st) == 0
 
 
 def test_config3_1000_steps_stay_physical(X):

@@ -131,6 +131,9 @@ class EngineSlab:
         B.check(self.L.fb_slab_info(self._h, *[C.byref(x) for x in v]))
         self.XL, self.KA, self.KF, self.kyA0, self.kyF0, self.field_groups, self.row_chunks = [x.value for x in v]
         assert world == 1 or (self.XL, self.KA, self.KF) == slab_geometry(nx, ny, world)      # one rank: one group of all columns at the engine's pitch
+        ng, cols = C.c_int(), (C.c_int * 2)()
+        B.check(self.L.fb_slab_col_groups(nx, ny, world, C.byref(ng), cols))
+        self.col_groups = [cols[g] for g in range(ng.value)]                                  # 2 entries: the stage is pipelined by column groups
         self._cb = None
         self.transport = "none"
         if world > 1:
