@@ -4,7 +4,7 @@
 root=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)
 cd "$root/xlab-fftbarotropic_amd" || exit 1
 log=${TMPDIR:-/tmp}/fb_build_report.log
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-value \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=on -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-value \
   -Rpass-analysis=kernel-resource-usage -o "${TMPDIR:-/tmp}/fb_build_report.so" csrc/fftbaro.hip csrc/fb_fields.cpp csrc/fb_fieldio.cpp csrc/fb_slab_comm.cpp -ldl $FB_EXTRA_FLAGS 2> "$log"
 rc=$?
 echo rc=$rc

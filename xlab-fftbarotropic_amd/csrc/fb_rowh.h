@@ -46,6 +46,10 @@ template <int V> struct RowH {
 struct RhNothing { FB_DEV void operator()() const {} };
 template <int V, bool LEAD = true, class F = RhNothing> FB_DEV void rh_xch_group(cf (*v)[8], cf *xbuf, int w, int l, F &&behind_barrier = F())
 {
+#ifdef FB_R8_NOXG   /* timing experiment only (results are wrong) */
+    behind_barrier();
+    return;
+#endif
     if (LEAD) lds_barrier();                          // every wave is done with its slices (not needed by the backward transforms: r8_xch_group)
 #pragma unroll
     for (int s = 0; s < V; ++s)
@@ -57,6 +61,35 @@ template <int V, bool LEAD = true, class F = RhNothing> FB_DEV void rh_xch_group
     for (int s = 0; s < V; ++s)
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[s][e] = lds_rd(&xbuf[s * RowH<V>::XSUB + w * Row8::SLICE + e * 64 + l]);
+}
+
+// The wave-private exchanges of the V sub-sequences, issued TOGETHER: all writes, one scheduling fence, all reads.  The sub-sequences
+// are independent (slices of their own), so the LDS round trip of one hides behind the other's instead of being paid V times, and
+// the butterflies that follow have two independent chains to schedule (a wave has one partner on its SIMD at ny = 16384).
+#ifndef RH_INTERLEAVE
+#define RH_INTERLEAVE 1
+#endif
+template <int V, bool HI> FB_DEV void rh_xch_wave_all(cf (*v)[8], cf *xbuf, int w, int l_hi, int l_lo)
+{
+#ifdef FB_R8_NOXW   /* timing experiment only (results are wrong) */
+    return;
+#endif
+    constexpr int PITCH = HI ? Row8::PITCH_HI : Row8::PITCH_LO;
+#pragma unroll
+    for (int s = 0; s < V; ++s) {
+        cf *wr = xbuf + s * RowH<V>::XSUB + w * Row8::SLICE + l_hi * 8 + l_lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lds_wr(&wr[e * PITCH], v[s][e]);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < V; ++s) {
+        const cf *slice = xbuf + s * RowH<V>::XSUB + w * Row8::SLICE;
+        const cf *rd = HI ? slice + l_hi * PITCH + l_lo : slice + l_lo * PITCH + l_hi * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[s][e] = lds_rd(&rd[e * (HI ? 8 : 1)]);
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // backward: natural order in, digit-reversed out: sub-transform output F_s[j'] with j' = w + 8 l_hi + 64 l_lo + 512 e; then
@@ -71,6 +104,27 @@ template <int V, class F> FB_DEV void rh_bwd(cf (*v)[8], cf *xbuf, const Row8Tw 
         for (int p = 1; p < 8; ++p) v[s][p] = cmulc(v[s][p], tw.w0[p - 1]);
     }
     rh_xch_group<V, false>(v, xbuf, w, l, behind_barrier);
+    if (V > 1 && RH_INTERLEAVE) {
+#pragma unroll
+        for (int s = 0; s < V; ++s) {
+            Bfly<8, +1>::run(v[s]);
+#pragma unroll
+            for (int p = 1; p < 8; ++p) v[s][p] = cmulc(v[s][p], tw.w1[p - 1]);
+        }
+        rh_xch_wave_all<V, true>(v, xbuf, w, l_hi, l_lo);
+        cf w2[7];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) w2[p - 1] = lds_rd(&tw.w2[p * 8 + l_lo]);
+#pragma unroll
+        for (int s = 0; s < V; ++s) {
+            Bfly<8, +1>::run(v[s]);
+#pragma unroll
+            for (int p = 1; p < 8; ++p) v[s][p] = cmulc(v[s][p], w2[p - 1]);
+        }
+        rh_xch_wave_all<V, false>(v, xbuf, w, l_hi, l_lo);
+#pragma unroll
+        for (int s = 0; s < V; ++s) Bfly<8, +1>::run(v[s]);
+    } else {
 #pragma unroll
     for (int s = 0; s < V; ++s) {
         cf *slice = xbuf + s * RowH<V>::XSUB + w * Row8::SLICE;
@@ -83,6 +137,7 @@ template <int V, class F> FB_DEV void rh_bwd(cf (*v)[8], cf *xbuf, const Row8Tw 
         for (int p = 1; p < 8; ++p) v[s][p] = cmulc(v[s][p], lds_rd(&tw.w2[p * 8 + l_lo]));
         r8_xch_wave<false>(v[s], slice, l_hi, l_lo);
         Bfly<8, +1>::run(v[s]);
+    }
     }
     if (V == 2) {
         cf wj[8];                                     // W^{-(jb + 512 e)} = conj(wq) * exp(+2 pi i e/16)
@@ -119,6 +174,27 @@ template <int V> FB_DEV void rh_fwd(cf (*v)[8], cf *xbuf, const Row8Tw &tw, cf w
             v[V - 1][e] = d;
         }
     }
+    if (V > 1 && RH_INTERLEAVE) {
+#pragma unroll
+        for (int s = 0; s < V; ++s) Bfly<8, -1>::run(v[s]);
+        rh_xch_wave_all<V, false>(v, xbuf, w, l_hi, l_lo);
+        cf w2[7];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) w2[p - 1] = lds_rd(&tw.w2[p * 8 + l_lo]);
+#pragma unroll
+        for (int s = 0; s < V; ++s) {
+#pragma unroll
+            for (int p = 1; p < 8; ++p) v[s][p] = cmul(v[s][p], w2[p - 1]);
+            Bfly<8, -1>::run(v[s]);
+        }
+        rh_xch_wave_all<V, true>(v, xbuf, w, l_hi, l_lo);
+#pragma unroll
+        for (int s = 0; s < V; ++s) {
+#pragma unroll
+            for (int p = 1; p < 8; ++p) v[s][p] = cmul(v[s][p], tw.w1[p - 1]);
+            Bfly<8, -1>::run(v[s]);
+        }
+    } else {
 #pragma unroll
     for (int s = 0; s < V; ++s) {
         cf *slice = xbuf + s * RowH<V>::XSUB + w * Row8::SLICE;
@@ -131,6 +207,7 @@ template <int V> FB_DEV void rh_fwd(cf (*v)[8], cf *xbuf, const Row8Tw &tw, cf w
 #pragma unroll
         for (int p = 1; p < 8; ++p) v[s][p] = cmul(v[s][p], tw.w1[p - 1]);
         Bfly<8, -1>::run(v[s]);
+    }
     }
     rh_xch_group<V>(v, xbuf, w, l);
 #pragma unroll
@@ -169,6 +246,13 @@ FB_DEV void rh_dma_issue(cf *stg, int t, const RowView &view, int field, int row
 template <int V> FB_DEV void rh_ext(cf (*v)[8], int t, const cf *stg, const cf *wx /*[V]: exp(+2 pi i (V t + s)/N)*/)
 {
     constexpr int M = RowH<V>::M;
+#ifdef FB_R8_NOEXT  /* timing experiment only (results are wrong): no staging reads, no pre-processing */
+#pragma unroll
+    for (int s = 0; s < V; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[s][e] = cf_make(wx[s].x + (float)e, wx[s].y);
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < V; ++s)
 #pragma unroll
@@ -228,7 +312,11 @@ __global__ void __launch_bounds__(512, RowH<V>::MIN_WAVES) k_rowh(RowArgs a, con
     __syncthreads();
 
     const int iters = (a.nx + gridDim.x - 1) / gridDim.x;
+#ifdef FB_ROW_SAMEROW   /* timing experiment only: every workgroup works on row 0 (no HBM traffic); results are wrong */
+    auto row_of = [&](int it, bool &valid) { const int r = it * gridDim.x + blockIdx.x; valid = r < a.nx; return a.x0; };
+#else
     auto row_of = [&](int it, bool &valid) { const int r = it * gridDim.x + blockIdx.x; valid = r < a.nx; return a.x0 + (valid ? r : 0); };
+#endif
     if (iters > 0) {
         bool vld; const int x = row_of(0, vld);
         rh_dma_issue<V, SLAB>(stg, t, a.M, 0, x);
@@ -300,7 +388,11 @@ __global__ void __launch_bounds__(512, RowH<V>::MIN_WAVES) k_rowh(RowArgs a, con
 #pragma unroll
             for (int e = 4; e < 8; ++e) lds_wr(&xbuf[V * (tt + 512 * (e - 4)) + s], v[s][e]);
         lds_barrier();
+#ifdef FB_R8_NOST   /* timing experiment only: (almost) no stores */
+        if (valid && v[0][0].x == 123.456f) {
+#else
         if (valid) {
+#endif
 #pragma unroll
             for (int s = 0; s < V; ++s)
 #pragma unroll
