@@ -67,8 +67,25 @@ template <int V, bool LEAD = true, class F = RhNothing> FB_DEV void rh_xch_group
 // are independent (slices of their own), so the LDS round trip of one hides behind the other's instead of being paid V times, and
 // the butterflies that follow have two independent chains to schedule (a wave has one partner on its SIMD at ny = 16384).
 #ifndef RH_INTERLEAVE
-#define RH_INTERLEAVE 1
+#define RH_INTERLEAVE 2
 #endif
+// one sub-sequence's wave-private exchange in two halves (RH_INTERLEAVE == 2: the other sub-sequence's butterfly is issued between
+// them, so that the LDS round trip of one hides behind the arithmetic of the other inside the same wave)
+template <int V, bool HI> FB_DEV void rh_xw_write(const cf *v, cf *xbuf, int s, int w, int l_hi, int l_lo)
+{
+    constexpr int PITCH = HI ? Row8::PITCH_HI : Row8::PITCH_LO;
+    cf *wr = xbuf + s * RowH<V>::XSUB + w * Row8::SLICE + l_hi * 8 + l_lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds_wr(&wr[e * PITCH], v[e]);
+}
+template <int V, bool HI> FB_DEV void rh_xw_read(cf *v, const cf *xbuf, int s, int w, int l_hi, int l_lo)
+{
+    constexpr int PITCH = HI ? Row8::PITCH_HI : Row8::PITCH_LO;
+    const cf *slice = xbuf + s * RowH<V>::XSUB + w * Row8::SLICE;
+    const cf *rd = HI ? slice + l_hi * PITCH + l_lo : slice + l_lo * PITCH + l_hi * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = lds_rd(&rd[e * (HI ? 8 : 1)]);
+}
 template <int V, bool HI> FB_DEV void rh_xch_wave_all(cf (*v)[8], cf *xbuf, int w, int l_hi, int l_lo)
 {
 #ifdef FB_R8_NOXW   /* timing experiment only (results are wrong) */
@@ -97,6 +114,25 @@ template <int V, bool HI> FB_DEV void rh_xch_wave_all(cf (*v)[8], cf *xbuf, int 
 template <int V, class F> FB_DEV void rh_bwd(cf (*v)[8], cf *xbuf, const Row8Tw &tw, cf wq, int w, int l, F &&behind_barrier)
 {
     const int l_hi = l >> 3, l_lo = l & 7;
+#if !defined(FB_R8_NOXG)
+    if (V > 1 && RH_INTERLEAVE == 2) {                    // the group exchange with sub-sequence s's values leaving while s + 1 is transformed
+#pragma unroll
+        for (int s = 0; s < V; ++s) {
+            Bfly<8, +1>::run(v[s]);
+#pragma unroll
+            for (int p = 1; p < 8; ++p) v[s][p] = cmulc(v[s][p], tw.w0[p - 1]);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) lds_wr(&xbuf[s * RowH<V>::XSUB + p * Row8::SLICE + w * 64 + l], v[s][p]);
+        }
+        lds_barrier();
+        behind_barrier();
+#pragma unroll
+        for (int s = 0; s < V; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[s][e] = lds_rd(&xbuf[s * RowH<V>::XSUB + w * Row8::SLICE + e * 64 + l]);
+    } else
+#endif
+    {
 #pragma unroll
     for (int s = 0; s < V; ++s) {
         Bfly<8, +1>::run(v[s]);
@@ -104,7 +140,30 @@ template <int V, class F> FB_DEV void rh_bwd(cf (*v)[8], cf *xbuf, const Row8Tw 
         for (int p = 1; p < 8; ++p) v[s][p] = cmulc(v[s][p], tw.w0[p - 1]);
     }
     rh_xch_group<V, false>(v, xbuf, w, l, behind_barrier);
-    if (V > 1 && RH_INTERLEAVE) {
+    }
+    if (V > 1 && RH_INTERLEAVE == 2) {
+        cf w2[7];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) w2[p - 1] = lds_rd(&tw.w2[p * 8 + l_lo]);
+#pragma unroll
+        for (int s = 0; s < V; ++s) {                  // write and send for s while s + 1 is still being transformed
+            Bfly<8, +1>::run(v[s]);
+#pragma unroll
+            for (int p = 1; p < 8; ++p) v[s][p] = cmulc(v[s][p], tw.w1[p - 1]);
+            rh_xw_write<V, true>(v[s], xbuf, s, w, l_hi, l_lo);
+            rh_xw_read<V, true>(v[s], xbuf, s, w, l_hi, l_lo);
+        }
+#pragma unroll
+        for (int s = 0; s < V; ++s) {
+            Bfly<8, +1>::run(v[s]);
+#pragma unroll
+            for (int p = 1; p < 8; ++p) v[s][p] = cmulc(v[s][p], w2[p - 1]);
+            rh_xw_write<V, false>(v[s], xbuf, s, w, l_hi, l_lo);
+            rh_xw_read<V, false>(v[s], xbuf, s, w, l_hi, l_lo);
+        }
+#pragma unroll
+        for (int s = 0; s < V; ++s) Bfly<8, +1>::run(v[s]);
+    } else if (V > 1 && RH_INTERLEAVE) {
 #pragma unroll
         for (int s = 0; s < V; ++s) {
             Bfly<8, +1>::run(v[s]);
@@ -174,7 +233,31 @@ template <int V> FB_DEV void rh_fwd(cf (*v)[8], cf *xbuf, const Row8Tw &tw, cf w
             v[V - 1][e] = d;
         }
     }
-    if (V > 1 && RH_INTERLEAVE) {
+    if (V > 1 && RH_INTERLEAVE == 2) {
+        cf w2[7];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) w2[p - 1] = lds_rd(&tw.w2[p * 8 + l_lo]);
+#pragma unroll
+        for (int s = 0; s < V; ++s) {
+            Bfly<8, -1>::run(v[s]);
+            rh_xw_write<V, false>(v[s], xbuf, s, w, l_hi, l_lo);
+            rh_xw_read<V, false>(v[s], xbuf, s, w, l_hi, l_lo);
+        }
+#pragma unroll
+        for (int s = 0; s < V; ++s) {
+#pragma unroll
+            for (int p = 1; p < 8; ++p) v[s][p] = cmul(v[s][p], w2[p - 1]);
+            Bfly<8, -1>::run(v[s]);
+            rh_xw_write<V, true>(v[s], xbuf, s, w, l_hi, l_lo);
+            rh_xw_read<V, true>(v[s], xbuf, s, w, l_hi, l_lo);
+        }
+#pragma unroll
+        for (int s = 0; s < V; ++s) {
+#pragma unroll
+            for (int p = 1; p < 8; ++p) v[s][p] = cmul(v[s][p], tw.w1[p - 1]);
+            Bfly<8, -1>::run(v[s]);
+        }
+    } else if (V > 1 && RH_INTERLEAVE) {
 #pragma unroll
         for (int s = 0; s < V; ++s) Bfly<8, -1>::run(v[s]);
         rh_xch_wave_all<V, false>(v, xbuf, w, l_hi, l_lo);
