@@ -575,6 +575,19 @@ def test_reference_pipeline_unmodified_runs_on_the_engine(tmp_path):
         runs[tag] = (res.stdout, (d / "log").read_text(), fm.stdout, len(pres))
     steps_of = lambda out: [ln for ln in out.splitlines() if ln.startswith("# Step")]
     assert steps_of(runs["ref"][0]) == steps_of(runs["own"][0]) and len(steps_of(runs["ref"][0])) == 1200
+    # the reference's plain driver main.cpp (no source path, rk4_c / dvortdt_c buffers: main.cpp:286-317), unmodified, on the same input
+    d = tmp_path / "ref_main"
+    (d / "input").mkdir(parents=True)
+    (d / "output").mkdir()
+    subprocess.check_call([os.path.join(REFDIR, "makefield-Kuo2004.out")], cwd=str(d), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    res = subprocess.run([os.path.join(LINKDIR, "main.out")], cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert steps_of(res.stdout) == steps_of(runs["own"][0]) and (d / "log").read_text() == runs["own"][1]
+    for step in (0, 500, 1100):
+        for name in ("vort", "psi", "u", "v"):
+            a = np.fromfile(str(d / "output" / ("%s_step_%d.bin" % (name, step))), dtype="<f4")
+            b = np.fromfile(str(tmp_path / "own" / "output" / ("%s_step_%d.bin" % (name, step))), dtype="<f4")
+            assert R.rel_l2(b, a) < 1e-5, ("main.cpp", name, step)
     assert runs["ref"][1] == runs["own"][1] and runs["ref"][3] == 12
     rd = lambda tag, f: np.fromfile(str(tmp_path / tag / "output" / f), dtype="<f4")
     worst = 0.0
