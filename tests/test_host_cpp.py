@@ -440,7 +440,7 @@ def test_driver_four_ranks_as_threads_match_the_single_gpu_run(tmp_path):
     exe, prod = os.path.join(HOST, "barotropic_main.out"), os.path.join(HOST, "vort_src_input.out")
     src_args = ["--npts", str(n), "--dt", "3", "--steps", str(steps), "--beg-time", "150", "--duration", "300"]   # on at step 50, off at 150
     outs = {}
-    for tag in ("one", "four"):
+    for tag in ("one", "four", "fan"):
         d = tmp_path / tag
         (d / "input").mkdir(parents=True)
         (d / "output").mkdir()
@@ -450,6 +450,12 @@ def test_driver_four_ranks_as_threads_match_the_single_gpu_run(tmp_path):
             os.mkfifo(str(d / "fifo"))
             procs.append(subprocess.Popen("%s %s > fifo" % (prod, " ".join(src_args)), shell=True, cwd=str(d), stderr=subprocess.DEVNULL))
             extra = []
+        elif tag == "fan":                                  # ONE producer of whole fields (what the reference ships); the lead rank fans its records out
+            os.mkfifo(str(d / "fifo"))
+            for r in range(world):
+                os.mkfifo(str(d / ("fifo.%d" % r)))
+            procs.append(subprocess.Popen("%s %s > fifo" % (prod, " ".join(src_args)), shell=True, cwd=str(d), stderr=subprocess.DEVNULL))
+            extra = ["--world", str(world), "--ranks-as-threads", "--fifo-fanout"]
         else:
             for r in range(world):
                 os.mkfifo(str(d / ("fifo.%d" % r)))
@@ -463,6 +469,7 @@ def test_driver_four_ranks_as_threads_match_the_single_gpu_run(tmp_path):
         assert res.returncode == 0, res.stderr[-2000:]
         outs[tag] = (res.stdout, (d / "log").read_text())
     assert outs["four"][0] == outs["one"][0] and outs["four"][1] == outs["one"][1]
+    assert outs["fan"][0] == outs["one"][0] and outs["fan"][1] == outs["one"][1]
     assert "# Step 200, time = 600.00, record now!" in outs["one"][0] and len(outs["one"][1].split()) == 15
     rd = lambda tag, f: np.fromfile(str(tmp_path / tag / "output" / f), dtype="<f4")
     for step in (0, 100, 200):
@@ -471,6 +478,8 @@ def test_driver_four_ranks_as_threads_match_the_single_gpu_run(tmp_path):
         assert np.array_equal(rd("one", "vort_src_input_step_%d.bin" % step), rd("four", "vort_src_input_step_%d.bin" % step))
         for name in ("psi", "u", "v"):
             assert R.rel_l2(rd("four", "%s_step_%d.bin" % (name, step)), rd("one", "%s_step_%d.bin" % (name, step))) < 1e-6, (name, step)
+        for f in ("vort", "psi", "u", "v", "vort_src_input"):                       # fanned-out source == per-rank producers, bit for bit
+            assert np.array_equal(rd("fan", "%s_step_%d.bin" % (f, step)).view(np.uint32), rd("four", "%s_step_%d.bin" % (f, step)).view(np.uint32)), (f, step)
     assert rd("one", "vort_src_input_step_100.bin").max() > 0 and rd("one", "vort_src_input_step_200.bin").max() == 0
 
 

@@ -52,9 +52,39 @@ struct Config {
     int npts = 768, record_step = 100, total_steps = -1, start_step = 0;          // configuration.hpp:18,35,36
     float LX = 600000.0f, LY = 600000.0f, NU = 6.5f, dt = 3.0f;                    // configuration.hpp:15-17,34
     RECIPE_TYPE recipe_type = EMPTY;
-    int world = 1, rank = 0; bool threads = false;
+    int world = 1, rank = 0; bool threads = false, fanout = false;
     long comm_max_age = 60, comm_timeout = 600;
 };
+
+// --fifo-fanout (multi-GPU, SURVEY.md section 8(e) "rank 0 reads, scatters x-slabs"): ONE producer that writes whole fields -- the
+// reference's unmodified vort_src_input.out -- feeds every rank.  The lead rank reads `<fifo>` (flag byte per step, GRIDS float32 after
+// a flag of 1: vorticity_source.cpp:112-133) and passes the same protocol on to `<fifo>.<r>`, each rank's x rows only; the ranks read
+// their `<fifo>.<r>` as they do when per-rank producers feed them.  The launcher creates the FIFOs.
+static void fifo_fanout(const Config cfg)
+{
+    const size_t slab = (size_t)(cfg.npts / cfg.world) * cfg.npts;
+    FILE *in = fopen(cfg.vort_src_filename.c_str(), "rb");
+    if (!in) { printf("ERROR: cannot open file [%s].\n", cfg.vort_src_filename.c_str()); return; }
+    std::vector<FILE *> out(cfg.world, nullptr);
+    for (int r = 0; r < cfg.world; ++r) {
+        const std::string fn = cfg.vort_src_filename + "." + std::to_string(r);
+        if ((out[r] = fopen(fn.c_str(), "wb")) == NULL) { printf("ERROR: cannot open file [%s].\n", fn.c_str()); return; }
+    }
+    std::vector<float> buf(slab);
+    char flag;
+    while (fread(&flag, 1, 1, in) == 1) {
+        for (FILE *f : out) { fwrite(&flag, 1, 1, f); if (((unsigned int)flag) != 1) fflush(f); }
+        if (((unsigned int)flag) != 1) continue;
+        bool ok = true;
+        for (int r = 0; r < cfg.world && ok; ++r) {                                    // the field is x-major: rank r's rows are the r-th piece of the record
+            ok = fread(buf.data(), sizeof(float), slab, in) == slab;
+            if (ok) { fwrite(buf.data(), sizeof(float), slab, out[r]); fflush(out[r]); }
+        }
+        if (!ok) break;                                                                // short record: the ranks report it as the reference does
+    }
+    for (FILE *f : out) fclose(f);                                                     // EOF for every rank ("No flag was detected")
+    fclose(in);
+}
 
 // ---- the source: VortSrcRecipeReader<GRIDS> (vorticity_source.cpp:48-135) with the FIFO read ahead of the step loop ------------
 // The byte protocol is the reference's: per step one flag byte, followed by `n` float32 when the flag is 1
@@ -355,7 +385,8 @@ int main(int argc, char *args[])
     static struct option lopts[] = {{"npts", 1, 0, 1}, {"lx", 1, 0, 2}, {"ly", 1, 0, 3}, {"nu", 1, 0, 4}, {"dt", 1, 0, 5},
                                     {"steps", 1, 0, 6}, {"record-step", 1, 0, 7}, {"start-step", 1, 0, 8},
                                     {"world", 1, 0, 9}, {"rank", 1, 0, 10}, {"comm-file", 1, 0, 11}, {"ranks-as-threads", 0, 0, 12},
-                                    {"launch-token", 1, 0, 13}, {"comm-max-age", 1, 0, 14}, {"comm-timeout", 1, 0, 15}, {0, 0, 0, 0}};
+                                    {"launch-token", 1, 0, 13}, {"comm-max-age", 1, 0, 14}, {"comm-timeout", 1, 0, 15}, {"fifo-fanout", 0, 0, 16},
+                                    {0, 0, 0, 0}};
     int opt;
     while ((opt = getopt_long(argc, args, "I:O:i:s:f:", lopts, NULL)) != EOF) {      // main.cpp:68-80, main-shallow-water.cpp:75-95
         switch (opt) {
@@ -379,6 +410,7 @@ int main(int argc, char *args[])
         case 13: cfg.token = optarg; break;              // the same string on every rank of one launch (job id, start time)
         case 14: cfg.comm_max_age = atol(optarg); break;
         case 15: cfg.comm_timeout = atol(optarg); break;
+        case 16: cfg.fanout = true; break;
         }
     }
     if (cfg.world < 1 || cfg.rank < 0 || cfg.rank >= cfg.world || (cfg.world > 1 && !cfg.threads && cfg.comm_file.empty()) ||
@@ -410,6 +442,8 @@ int main(int argc, char *args[])
 
     FILE *log_fd = lead ? fopen("log", "w") : fopen("/dev/null", "w");                // main.cpp:97
     if (log_fd == NULL) { perror("Open log file"); return 1; }
+    std::thread fan;
+    if (cfg.fanout && cfg.world > 1 && cfg.recipe_type == FIFO && lead) fan = std::thread(fifo_fanout, cfg);
     if (cfg.world > 1 && cfg.threads) {
         void *hub = nullptr;
         must(fb_local_hub_create(&hub, cfg.world), "fb_local_hub_create");
@@ -418,6 +452,7 @@ int main(int argc, char *args[])
         for (auto &t : ts) t.join();
         fb_local_hub_destroy(hub);
     } else run_rank(cfg, cfg.rank, nullptr, log_fd, lead);
+    if (fan.joinable()) fan.detach();                                                // (a producer that outlives the run keeps it inside fread)
     fclose(log_fd);
     if (lead) printf("Program ends. Congrats!\n");
     return 0;
