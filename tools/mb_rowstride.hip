@@ -11,7 +11,8 @@
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 
-__global__ void __launch_bounds__(256) k_tiles(float2 *data, long fstride, int P, int nct, int S, long ntiles)
+// OUT: 0 = in place (the kernel's way), otherwise the tile is written to the same position of a second set of arrays `OUT` bytes further on
+__global__ void __launch_bounds__(256) k_tiles(float2 *data, long fstride, int P, int nct, int S, long ntiles, size_t out_off)
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c16 = lane & 15;
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(256) k_tiles(float2 *data, long fstride, int P
             for (int q = 0; q < 8; ++q) {
                 const int k = h + 4 * s + 16 * q;
                 f2v o = {acc.x + (float)k, acc.y};
-                *reinterpret_cast<f2v *>(base + (size_t)k * S * P + c16) = o;
+                *reinterpret_cast<f2v *>(base + out_off + (size_t)k * S * P + c16) = o;
             }
     }
 }
@@ -67,20 +68,22 @@ int main(int argc, char **argv)
 {
     const int nx = 16384, P = 8208, nct = 488;                      // active 16-column tiles at 16384^2
     const size_t n = (size_t)nx * P;
-    float2 *d; CK(hipMalloc(&d, 4 * n * sizeof(float2)));
-    CK(hipMemset(d, 0, 4 * n * sizeof(float2)));
+    float2 *d; CK(hipMalloc(&d, 8 * n * sizeof(float2)));
+    CK(hipMemset(d, 0, 8 * n * sizeof(float2)));
     const long ntiles = 4L * 128 * nct;
     const double bytes = 2.0 * ntiles * 128 * 128;                  // read + write, 128 rows x 128 B per tile
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int grids[] = {2048, 8192};
     for (int grid : grids)
         for (int S : {128, 32, 16, 4, 1}) {
-            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k_tiles, dim3(grid), dim3(256), 0, 0, d, (long)n, P, nct, S, ntiles);
+            for (size_t off : {(size_t)0, 4 * n}) {
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k_tiles, dim3(grid), dim3(256), 0, 0, d, (long)n, P, nct, S, ntiles, off);
             (void)hipDeviceSynchronize(); (void)hipEventRecord(e0, 0);
-            for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_tiles, dim3(grid), dim3(256), 0, 0, d, (long)n, P, nct, S, ntiles);
+            for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_tiles, dim3(grid), dim3(256), 0, 0, d, (long)n, P, nct, S, ntiles, off);
             (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5;
-            printf("grid %5d  rows %3d apart : %.3f ms per launch, %.0f GB/s\n", grid, S, ms, bytes / ms / 1e6);
+            printf("grid %5d  rows %3d apart %s : %.3f ms per launch, %.0f GB/s\n", grid, S, off ? "out of place" : "in place    ", ms, bytes / ms / 1e6);
+            }
         }
     {
         const int nct2 = nct / 2;
