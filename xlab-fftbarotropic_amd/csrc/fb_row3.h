@@ -14,13 +14,60 @@
 
 template <int M> struct Row3Cfg {
     static constexpr int N = 3 * M, T = M / 16, PT = 3 * T;
-    static constexpr int THREADS = 192;
+#ifndef FB_ROW3_THREADS
+    // one row pair per workgroup where a pair fills most of a wave (768: 48 threads), else as many pairs as fit 64 threads: the
+    // 3*2^k grids are small, and four pairs per 192-thread workgroup left 768^2 with 96 workgroups for 256 CUs
+    static constexpr int THREADS = PT >= 48 ? PT : (64 / PT) * PT;
+#else
+    static constexpr int THREADS = FB_ROW3_THREADS;
+#endif
     static constexpr int GP = THREADS / PT;                 // row pairs per workgroup
     static constexpr int LSTR = M + M / 16;                 // padded complex per sub-transform buffer
     static constexpr bool SHARE = RowPlanSymmetric<M>::value;
     static constexpr int TWL_B = RowTwSrc<M, false, true>::LDS_CF, TWL_F = SHARE ? 0 : RowTwSrc<M, true, true>::LDS_CF;
-    static constexpr size_t LDS_BYTES = ((size_t)GP * 3 * LSTR + TWL_B + TWL_F) * sizeof(cf);
+    // fused mode: the four half-spectrum rows of an x row staged in LDS (coalesced 16-byte loads, once) instead of every sub-transform
+    // group gathering all three thirds of both rows from global memory, 8 bytes at a time
+    static constexpr int HP = N / 2 + 2;                    // staged row: X[0 .. N/2] + one pad element (even length)
+    static constexpr int STG = 4 * HP;
+    static constexpr size_t LDS_BYTES = ((size_t)GP * 3 * LSTR + TWL_B + TWL_F + (size_t)GP * STG) * sizeof(cf);
 };
+#ifndef FB_ROW3_STAGE
+#define FB_ROW3_STAGE 1
+#endif
+
+// the four fields' half-spectrum rows of x row `row` -> stg[f * HP + k]; q = thread within the pair's PT threads
+template <int M, bool SLAB>
+FB_DEV void row3_stage4(cf *stg, int q, const RowView &v, int row)
+{
+    using C = Row3Cfg<M>;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+        for (int i = q; i < C::HP / 2; i += C::PT) {
+            const float4 x = *reinterpret_cast<const float4 *>(row_ptr<SLAB>(v, f, row, 2 * i));     // columns 2i, 2i+1 (the last pair: N/2 and a zero pad column)
+            *reinterpret_cast<float4 *>(&stg[f * C::HP + 2 * i]) = x;
+        }
+}
+template <int N> FB_DEV cf row3_z_lds(const cf *sa, const cf *sb, int k)
+{
+    const bool mirror = 2 * k > N;
+    const int kk = mirror ? N - k : k;
+    const cf a = sa[kk], b = sb[kk];
+    if (kk == 0 || 2 * kk == N) return cf_make(a.x, b.x);                     // Im ignored at k = 0 and k = N/2
+    return mirror ? cf_make(a.x + b.y, b.x - a.y) : cf_make(a.x - b.y, a.y + b.x);
+}
+template <int M>
+FB_DEV void row3_load_lds(cf *reg, int r, int t, const cf *sa, const cf *sb, const cf *__restrict__ twN)
+{
+    constexpr int N = 3 * M, T = M / 16, R0 = RowTw<M, false>::radix(0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int p0 = t + ord_i<R0>(e) * T;
+        cf z0 = row3_z_lds<N>(sa, sb, p0), z1 = row3_z_lds<N>(sa, sb, p0 + M), z2 = row3_z_lds<N>(sa, sb, p0 + 2 * M);
+        fft3<+1>(z0, z1, z2);
+        const cf g = r == 0 ? z0 : (r == 1 ? z1 : z2);
+        reg[e] = r == 0 ? g : cmulc(g, twN[r * p0]);
+    }
+}
 
 // Hermitian-extended packed spectrum value Z[k], 0 <= k < N, of the two half-spectrum rows A, B
 template <int N, bool SLAB>
@@ -98,6 +145,7 @@ __global__ void __launch_bounds__(Row3Cfg<M>::THREADS) k_row3(RowArgs a, const c
     cf *lds_pair = smem + (size_t)gp * 3 * C::LSTR;
     cf *lds = lds_pair + r * C::LSTR;
     cf *twl = smem + (size_t)GP * 3 * C::LSTR;
+    cf *stg = twl + C::TWL_B + C::TWL_F + (size_t)gp * C::STG;
     RowTwSrc<M, false, true> twb;
     twb.init(a.tw_bwd, twl, t, tid, C::THREADS);
     RowTwSrc<M, true, true> twf_own;
@@ -120,11 +168,17 @@ __global__ void __launch_bounds__(Row3Cfg<M>::THREADS) k_row3(RowArgs a, const c
             for (int rr = 0; rr < 2; ++rr) {
                 const int x = x0 + rr;
                 float zx[16], zy[16];
-                row3_load<M, SLAB>(reg, r, launder(t), a.M, 0, 1, x, x, twN);
+                if (FB_ROW3_STAGE) {
+                    __syncthreads();                                  // the previous row's readers are done with the staged rows
+                    row3_stage4<M, SLAB>(stg, launder(q), a.M, x);
+                    __syncthreads();
+                    row3_load_lds<M>(reg, r, launder(t), stg, stg + C::HP, twN);
+                } else row3_load<M, SLAB>(reg, r, launder(t), a.M, 0, 1, x, x, twN);
                 row_fft<M, false>(lds, launder(t), twb, reg);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { zx[e] = reg[e].x * a.scale; zy[e] = reg[e].y * a.scale; }   // main.cpp:154,168
-                row3_load<M, SLAB>(reg, r, launder(t), a.M, 2, 3, x, x, twN);
+                if (FB_ROW3_STAGE) row3_load_lds<M>(reg, r, launder(t), stg + 2 * C::HP, stg + 3 * C::HP, twN);
+                else row3_load<M, SLAB>(reg, r, launder(t), a.M, 2, 3, x, x, twN);
                 row_fft<M, false>(lds, launder(t), twb, reg);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {

@@ -563,6 +563,8 @@ template <int M, int MODE> static int launch_row3_t(fb_ctx *c, const RowArgs &a)
     if (grid > c->max_wg) grid = c->max_wg;
     const bool slab = c->world > 1;
     auto kern = slab ? k_row3<M, MODE, true> : k_row3<M, MODE, false>;
+    int rc = set_max_lds(c, (const void *)kern, C::LDS_BYTES);
+    if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::THREADS), C::LDS_BYTES, c->stream, a, (const cf *)c->d_tw_row3);
     HIPCHK(hipGetLastError());
     return FB_OK;
