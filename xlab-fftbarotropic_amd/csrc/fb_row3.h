@@ -14,14 +14,16 @@
 
 template <int M> struct Row3Cfg {
     static constexpr int N = 3 * M, T = M / 16, PT = 3 * T;
-#ifndef FB_ROW3_THREADS
-    // one row pair per workgroup where a pair fills most of a wave (768: 48 threads), else as many pairs as fit 64 threads: the
-    // 3*2^k grids are small, and four pairs per 192-thread workgroup left 768^2 with 96 workgroups for 256 CUs
-    static constexpr int THREADS = PT >= 48 ? PT : (64 / PT) * PT;
-#else
-    static constexpr int THREADS = FB_ROW3_THREADS;
-#endif
-    static constexpr int GP = THREADS / PT;                 // row pairs per workgroup
+    // M = 256 (768^2, the reference's default): TWO groups of PT = 48 working threads per workgroup, each on a wave of its own.  In the
+    // fused pass they take the two x rows of ONE row pair side by side (the pair's backward transforms used to run one row after the
+    // other in one group: five dependent transforms per workgroup on a grid with 384 row pairs for 256 CUs); elsewhere they are two
+    // independent pairs.  Larger M has at least as many row pairs as the chip has room for (measured at 1536^2: 0.069 ms with one
+    // group per workgroup, 0.101 ms with two), smaller M packs as many pairs as fit 64 threads.
+    static constexpr bool TWO = M == 256;
+    static constexpr int HS = TWO ? 64 : PT;                    // threads per group
+    static constexpr int GP = TWO ? 2 : (PT >= 48 ? 1 : 64 / PT);   // groups per workgroup
+    static constexpr int THREADS = GP * HS;
+    static constexpr int VALB = TWO ? 16 * PT : 0;              // complex: the two rows' tendency values handed between the groups (2 x 16 x PT floats)
     static constexpr int LSTR = M + M / 16;                 // padded complex per sub-transform buffer
     static constexpr bool SHARE = RowPlanSymmetric<M>::value;
     static constexpr int TWL_B = RowTwSrc<M, false, true>::LDS_CF, TWL_F = SHARE ? 0 : RowTwSrc<M, true, true>::LDS_CF;
@@ -29,7 +31,7 @@ template <int M> struct Row3Cfg {
     // group gathering all three thirds of both rows from global memory, 8 bytes at a time
     static constexpr int HP = N / 2 + 2;                    // staged row: X[0 .. N/2] + one pad element (even length)
     static constexpr int STG = 4 * HP;
-    static constexpr size_t LDS_BYTES = ((size_t)GP * 3 * LSTR + TWL_B + TWL_F + (size_t)GP * STG) * sizeof(cf);
+    static constexpr size_t LDS_BYTES = ((size_t)GP * 3 * LSTR + TWL_B + TWL_F + (size_t)GP * STG + VALB) * sizeof(cf);
 };
 #ifndef FB_ROW3_STAGE
 #define FB_ROW3_STAGE 1
@@ -141,11 +143,16 @@ __global__ void __launch_bounds__(Row3Cfg<M>::THREADS) k_row3(RowArgs a, const c
     constexpr int RL = RowTw<M, false>::radix(RowPlan<M>::S - 1);      // physical-space register order
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf *smem = reinterpret_cast<cf *>(smem_raw);
-    const int tid = threadIdx.x, gp = tid / PT, q = tid - gp * PT, r = q / T, t = q - r * T;
+    constexpr bool PAIR2 = C::TWO && MODE == ROW_FUSED;        // the two groups work on the two rows of one pair
+    constexpr int PPW = PAIR2 ? 1 : GP;                         // row pairs per workgroup
+    const int tid = threadIdx.x, gp = tid / C::HS, q0 = tid - gp * C::HS;
+    const bool active = q0 < PT;                                // (groups sit on whole waves: the lanes beyond PT repeat thread 0's work and store nothing)
+    const int q = active ? q0 : 0, r = q / T, t = q - r * T;
     cf *lds_pair = smem + (size_t)gp * 3 * C::LSTR;
     cf *lds = lds_pair + r * C::LSTR;
     cf *twl = smem + (size_t)GP * 3 * C::LSTR;
     cf *stg = twl + C::TWL_B + C::TWL_F + (size_t)gp * C::STG;
+    float *valb = reinterpret_cast<float *>(twl + C::TWL_B + C::TWL_F + (size_t)GP * C::STG);
     RowTwSrc<M, false, true> twb;
     twb.init(a.tw_bwd, twl, t, tid, C::THREADS);
     RowTwSrc<M, true, true> twf_own;
@@ -153,14 +160,43 @@ __global__ void __launch_bounds__(Row3Cfg<M>::THREADS) k_row3(RowArgs a, const c
     __syncthreads();
 
     const int npairs = a.nx >> 1;
-    const int iters = (npairs + gridDim.x * GP - 1) / (gridDim.x * GP);
+    const int iters = (npairs + gridDim.x * PPW - 1) / (gridDim.x * PPW);
     for (int it = 0; it < iters; ++it) {
-        const int pr = (it * gridDim.x + blockIdx.x) * GP + gp;
-        const bool valid = pr < npairs;
-        const int x0 = a.x0 + (valid ? 2 * pr : 0), x1 = x0 + 1;
+        const int pr = (it * gridDim.x + blockIdx.x) * PPW + (PAIR2 ? 0 : gp);
+        const bool valid = pr < npairs && active && (!PAIR2 || gp == 0);     // who stores
+        const int x0 = a.x0 + (pr < npairs ? 2 * pr : 0), x1 = x0 + 1;
         const int tl = launder(t);
         cf reg[16];
-        if (MODE == ROW_FUSED) {
+        if (PAIR2) {
+            // this group's row of the pair: four backward transforms' worth of work split over the two groups
+            const int x = x0 + gp;
+            float zx[16], zy[16], val[16];
+            __syncthreads();                                      // the previous pair's readers are done with the staged rows and the value buffer
+            row3_stage4<M, SLAB>(stg, launder(q), a.M, x);
+            __syncthreads();
+            row3_load_lds<M>(reg, r, launder(t), stg, stg + C::HP, twN);
+            row_fft<M, false>(lds, launder(t), twb, reg);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { zx[e] = reg[e].x * a.scale; zy[e] = reg[e].y * a.scale; }   // main.cpp:154,168
+            row3_load_lds<M>(reg, r, launder(t), stg + 2 * C::HP, stg + 3 * C::HP, twN);
+            row_fft<M, false>(lds, launder(t), twb, reg);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float u = -(reg[e].x * a.scale);            // main.cpp:200-201
+                const float v = reg[e].y * a.scale;               // main.cpp:214
+                const int y = 3 * (tl + ord_i<RL>(e) * T) + r;
+                const float s = a.src ? a.src[(size_t)x * N + y] : 0.0f;
+                val[e] = -u * zx[e] - v * zy[e] + s;              // main.cpp:225-227
+            }
+            // both rows' values to both groups: the forward transform packs row x0 (real part) and row x0 + 1 (imaginary part); both
+            // groups run it (a barrier inside it must be met by every wave), group 0 stores
+            const int ql = launder(q);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) valb[(gp * 16 + e) * PT + ql] = val[e];
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; ++e) reg[e] = cf_make(valb[e * PT + ql], valb[(16 + e) * PT + ql]);
+        } else if (MODE == ROW_FUSED) {
             float t0[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) t0[e] = 0.f;

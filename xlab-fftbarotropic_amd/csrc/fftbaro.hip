@@ -559,7 +559,8 @@ template <int M, int MODE> static int launch_row3_t(fb_ctx *c, const RowArgs &a)
 {
     using C = Row3Cfg<M>;
     const int npairs = a.nx / 2;
-    int grid = (npairs + C::GP - 1) / C::GP;
+    constexpr int ppw = (C::TWO && MODE == ROW_FUSED) ? 1 : C::GP;     // row pairs per workgroup (fb_row3.h)
+    int grid = (npairs + ppw - 1) / ppw;
     if (grid > c->max_wg) grid = c->max_wg;
     const bool slab = c->world > 1;
     auto kern = slab ? k_row3<M, MODE, true> : k_row3<M, MODE, false>;
