@@ -214,7 +214,16 @@ template <int N> struct RowCfg {
     static constexpr bool RES = RowRes<N>::value;
     static constexpr bool SHARE = RES && RowPlanSymmetric<N>::value;        // one twiddle set for both directions
     static constexpr int TWL_B = RowTwSrc<N, false, RES>::LDS_CF, TWL_F = SHARE ? 0 : RowTwSrc<N, true, RES>::LDS_CF;
-    static constexpr size_t LDS_BYTES = ((size_t)G * GSTR + TWL_B + TWL_F) * sizeof(cf);
+    // Small grids (N <= 1024: a few hundred row pairs for 256 CUs) are bound by the chain of five dependent transforms a row pair
+    // takes in one thread group.  There the fused pass gives a pair TWO groups, one per x row, side by side: each runs its row's two
+    // backward transforms, they hand their tendency values to each other through LDS, both run the packed forward transform (its
+    // barriers must be met by every wave), the even group stores.  (As k_row3 at 768^2: 0.054 -> 0.035 ms per launch.)
+#ifndef FB_PAIR2_MAXN
+#define FB_PAIR2_MAXN 1024   /* 2048^2 has enough row pairs to fill the chip: measured below */
+#endif
+    static constexpr bool PAIR2 = N <= FB_PAIR2_MAXN && G >= 2;
+    static constexpr int VALB = PAIR2 ? G * 8 * T : 0;                     // complex: 16 floats per thread and group
+    static constexpr size_t LDS_BYTES = ((size_t)G * GSTR + TWL_B + TWL_F + VALB) * sizeof(cf);
     static constexpr int MIN_WAVES = HALFX ? 3 : (THREADS == 256 ? 2 : (THREADS == 512 ? 2 : 4));
 };
 
@@ -354,11 +363,15 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
     cf *lds = smem + (size_t)grp * C::GSTR;
     cf *stg = lds + C::LSTR;
     const int npairs = a.nx >> 1;
-    const int iters = (npairs + gridDim.x * G - 1) / (gridDim.x * G);
+    constexpr bool PAIR2 = C::PAIR2 && MODE == ROW_FUSED;      // two groups per row pair, one per x row (RowCfg)
+    constexpr int PPW = PAIR2 ? G / 2 : G;                      // row pairs per workgroup
+    const int pgrp = PAIR2 ? grp >> 1 : grp, half = PAIR2 ? grp & 1 : 0;
+    const int iters = (npairs + gridDim.x * PPW - 1) / (gridDim.x * PPW);
 
     // stage twiddles: once per workgroup (registers + a small LDS table) for N <= 4096, streamed otherwise
     constexpr bool SHARE = C::SHARE;
     cf *twl = smem + (size_t)G * C::GSTR;
+    float *valb = reinterpret_cast<float *>(twl + C::TWL_B + C::TWL_F);
     RowTwSrc<N, false, C::RES> twb;
     twb.init(a.tw_bwd, twl, t, threadIdx.x, C::THREADS);
     RowTwSrc<N, true, C::RES> twf_own;
@@ -366,13 +379,13 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
     __syncthreads();
 
 #ifdef FB_ROW_SAMEROW   /* timing experiment only: every workgroup works on rows 0,1 (no HBM traffic); results are wrong */
-    auto pair_of = [&](int it, bool &valid) { const int pr = (it * gridDim.x + blockIdx.x) * G + grp; valid = pr < npairs; return a.x0; };
+    auto pair_of = [&](int it, bool &valid) { const int pr = (it * gridDim.x + blockIdx.x) * PPW + pgrp; valid = pr < npairs; return a.x0; };
 #else
-    auto pair_of = [&](int it, bool &valid) { const int pr = (it * gridDim.x + blockIdx.x) * G + grp; valid = pr < npairs; return a.x0 + (valid ? 2 * pr : 0); };
+    auto pair_of = [&](int it, bool &valid) { const int pr = (it * gridDim.x + blockIdx.x) * PPW + pgrp; valid = pr < npairs; return a.x0 + (valid ? 2 * pr : 0); };
 #endif
     cf nyqA = cf_make(0.f, 0.f), nyqB = nyqA;
     if (DMA && iters > 0) {                                   // prologue: phase 0 of the first pair
-        bool v; const int x = pair_of(0, v);
+        bool v; const int x = pair_of(0, v) + half;
         row_dma_issue<N, SLAB>(stg, t, a.M, 0, 1, x, x, nyqA, nyqB);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -383,7 +396,50 @@ __global__ void __launch_bounds__(RowCfg<N>::THREADS, RowCfg<N>::MIN_WAVES) k_ro
         cf reg[16];
         const int t_it = launder(t);   (void)t_it;
 
-        if (MODE == ROW_FUSED) {
+        if constexpr (PAIR2) {
+            // this group's x row of the pair (x0 + half); the other group takes the other row at the same time
+            const int x = x0 + half;
+            float zx[16], zy[16];
+            if (DMA) {                                            // (this row's first two fields were waited for before the previous stores)
+                lds_barrier();
+                row_ext_from_stage<N>(reg, launder(t), stg, nyqA, nyqB);
+                lds_barrier();
+                row_dma_issue<N, SLAB>(stg, launder(t), a.M, 2, 3, x, x, nyqA, nyqB);
+            } else row_load_pair<N, SLAB>(reg, launder(t), a.M, 0, 1, x, x);
+            rowfft<N, false>(lds, launder(t), twb, reg);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { zx[e] = reg[e].x * a.scale; zy[e] = reg[e].y * a.scale; }   // main.cpp:154,168
+            if (DMA) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();
+                row_ext_from_stage<N>(reg, launder(t), stg, nyqA, nyqB);
+                lds_barrier();
+                bool vn = true;
+                const int xn = (it + 1 < iters) ? pair_of(it + 1, vn) + half : -1;
+                if (xn >= 0) row_dma_issue<N, SLAB>(stg, launder(t), a.M, 0, 1, xn, xn, nyqA, nyqB);
+            } else row_load_pair<N, SLAB>(reg, launder(t), a.M, 2, 3, x, x);
+            rowfft<N, false>(lds, launder(t), twb, reg);
+            float val[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float u = -(reg[e].x * a.scale);                // main.cpp:200-201
+                const float v = reg[e].y * a.scale;                   // main.cpp:214
+                val[e] = -u * zx[e] - v * zy[e];                      // main.cpp:225-227 ...
+            }
+            if (a.src) {                                              // ... + vort_src; the loads and their wait stay in this branch
+#pragma unroll
+                for (int e = 0; e < 16; ++e) val[e] += a.src[(size_t)x * N + t_it + ord_i<RL>(e) * T];
+            }
+            // both rows' values to both groups: the forward transform packs row x0 (real part) with row x0 + 1 (imaginary part)
+            const int tv = launder(t);
+            lds_barrier();                                            // (the previous pair's readers are done with the value buffer)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) valb[(grp * 16 + e) * T + tv] = val[e];
+            lds_barrier();
+#pragma unroll
+            for (int e = 0; e < 16; ++e) reg[e] = cf_make(valb[((grp & ~1) * 16 + e) * T + tv], valb[((grp | 1) * 16 + e) * T + tv]);
+            valid = valid && half == 0;                               // the even group stores
+        } else if (MODE == ROW_FUSED) {
             float t0[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) t0[e] = 0.f;

@@ -540,7 +540,8 @@ template <int N, int MODE> static int launch_row_t(fb_ctx *c, const RowArgs &a)
 {
     using C = RowCfg<N>;
     const int npairs = a.nx / 2;
-    int grid = (npairs + C::G - 1) / C::G;
+    constexpr int ppw = (C::PAIR2 && MODE == ROW_FUSED) ? C::G / 2 : C::G;      // row pairs per workgroup (fb_kernels.h, RowCfg)
+    int grid = (npairs + ppw - 1) / ppw;
     int cap = c->max_wg / 2;                  // persistent-style grid: a few workgroups per CU, each loops over row pairs
     if (const char *e = getenv("FB_ROW_GRID")) { int v = atoi(e); if (v >= 64) cap = v; }
     if (grid > cap) grid = cap;
