@@ -668,6 +668,9 @@ struct MidArgs {
     float nu, dt;
     SpecCoef coef;
     const cf *tw_n, *tw_big;
+    int split;           // 1: small launch (fewer tiles than the chip has room for): ONE tile per workgroup, every wave repeats the forward
+                         // sub-pass and the update, wave 0 stores the state, wave f sends derivative field f through its backward sub-pass --
+                         // two dependent transforms per wave instead of five
 };
 
 // Memory discipline (gfx9 counts loads AND stores on vmcnt, returned in order): a wave that waits for a
@@ -690,7 +693,8 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
     __syncthreads();
     const int ntc = a.nct, ntc_all = a.P >> 4;
     const long ntiles = (long)a.N1 * ntc;
-    for (long wt = (long)blockIdx.x * 4 + wv; wt < ntiles; wt += (long)gridDim.x * 4) {
+    const bool split = a.split != 0;                 // (uniform; every wave of a workgroup then runs the same tiles, so the barriers below are met by all)
+    for (long wt = split ? (long)blockIdx.x : (long)blockIdx.x * 4 + wv; wt < ntiles; wt += split ? (long)gridDim.x : (long)gridDim.x * 4) {
         // per-tile opaque lane id: keeps address/coefficient arithmetic out of loop-invariant registers
         const int lane = launder((int)(threadIdx.x & 63));
         const int g = lane >> 3, cp = lane & 7, h = lane >> 4, c = lane & 15;
@@ -792,10 +796,11 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
                             update(e + 1, cf_make(q0[j].z, q0[j].w), cf_make(zq.z, zq.w), cf_make(q2[j].z, q2[j].w), acc1, zn[e + 1]);
                             q2[j] = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
                         }
+                        if (split) __syncthreads();          // every wave has read the old state before wave 0 overwrites it
 #pragma unroll
                         for (int j = 0; j < JH; ++j) {
                             const int jp = hb * JH + j, e = 2 * jp;
-                            if (frozen[j]) continue;
+                            if (frozen[j] || (split && wv != 0)) continue;
                             const float4 zo = make_float4(zn[e].x, zn[e].y, zn[e + 1].x, zn[e + 1].y);
                             if (a.stage < 3) {
                                 st4<(FB_NT & 64) != 0>(reinterpret_cast<float4 *>(a.Acc) + sb + jp * 64, q2[j]);
@@ -813,9 +818,11 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
                     }
 #pragma unroll
                     for (int e = 0; e < W::NLB; ++e) update(e, z0[e], zc[e], ac[e], ac[e], zn[e]);
+                    if (split) __syncthreads();              // (every wave has lanes in here) the old state has been read by all before wave 0 overwrites it
 #pragma unroll
                     for (int e = 0; e < W::NLB; ++e) {
                         const size_t off = tbase + (size_t)(h + 4 * (e >> 3) + W::R1 * (e & 7)) * a.P + c;
+                        if (split && wv != 0) continue;
                         if (a.stage < 3) { a.Acc[off] = ac[e]; a.Zcur[off] = zn[e]; }
                         else a.Zout[off] = zn[e];
                     }
@@ -845,12 +852,12 @@ __global__ void __launch_bounds__(256, WaveTile<n>::MID_MIN_WAVES) k_col_mid(Mid
         // derivatives of zn through the backward block sub-pass: f0 gradx(vort), f1 grady(vort),
         // then zn <- psi = invertLaplacian(vort) in place, f2 grady(psi), f3 gradx(psi)
 #pragma unroll 1
-        for (int f = 0; f < 4; ++f) {
+        for (int f = split ? wv : 0; f < (split ? wv + 1 : 4); ++f) {
             const int lf = launder(lane);
             const int gf = lf >> 3, cpf = lf & 7, hf = lf >> 4;
             cf fld[W::NLB];
             if (lb) {
-                if (f == 2) {
+                if (f == 2 || (split && f == 3)) {
 #pragma unroll
                     for (int s = 0; s < W::NP; ++s)
 #pragma unroll

@@ -717,11 +717,17 @@ template <int DIR> static int launch_col_block(fb_ctx *c, const ColGroup &G, cf 
     return FB_OK;
 }
 
-static int launch_col_mid(fb_ctx *c, const MidArgs &a)
+static int launch_col_mid(fb_ctx *c, const MidArgs &a0)
 {
-    if (a.nct <= 0) return FB_OK;
+    if (a0.nct <= 0) return FB_OK;
+    MidArgs a = a0;
     const long ntiles = (long)c->N1 * a.nct;
-    const dim3 g(col_grid(c, ntiles)), b(256);
+    // small launches of small tiles (grids up to 1024^2): one tile per workgroup, the derivative fields spread over its four waves
+    // (fb_kernels.h, MidArgs::split): 256^2 9072 -> 9808 steps/s, 1024^2 6084 -> 6382.  Not for 64-row tiles (the slabs of a 4096^2
+    // multi-GPU rank: 0.336 -> 0.383 ms per step) nor for 2048^2 (0.026 -> 0.038 ms per launch).  FB_MID_SPLIT=0|1 overrides
+    a.split = (ntiles <= 2048 && c->N2 <= 32) ? 1 : 0;
+    if (const char *e = getenv("FB_MID_SPLIT")) a.split = e[0] == '1';
+    const dim3 g(a.split ? (unsigned)(ntiles < c->max_wg ? ntiles : c->max_wg) : (unsigned)col_grid(c, ntiles)), b(256);
     switch (c->N2) {
     case 8: hipLaunchKernelGGL((k_col_mid<8>), g, b, 0, c->stream, a); break;
     case 16: hipLaunchKernelGGL((k_col_mid<16>), g, b, 0, c->stream, a); break;
