@@ -136,7 +136,7 @@ def cpu_baseline(n, dt, kind, steps, source=False):
             "other_configs_steps_per_s": small}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -150,25 +150,286 @@ def main():
     ap.add_argument("--spinup-steps", type=int, default=None,
                     help="untimed device spin-up before the warm-up: this many steps, then the state is reset (default: ~30 ms worth; 0 = none)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
-    args = ap.parse_args()
+    ap.add_argument("--also-grid", default="auto",
+                    help="N>1: further grids run in the same job as `configs_run` (comma separated; 'auto' = 8192 at N=4 -- BASELINE configs[3] -- "
+                         "and 16384 at N=8 -- configs[4]; 'none' = only --grid)")
+    ap.add_argument("--driver-steps", type=int, default=None,
+                    help="N=1: the `driver` leg -- the C++ drop-in driver (host/barotropic_main.out) on the same workload for this many steps with "
+                         "record_step 100 (configuration.hpp:34-36), records into a temporary directory (default: 1000 at the default grid, else 0 = off)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N>1 started from a plain shell: seconds before the child job is ended")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell (N > 1, no WORLD_SIZE): start the ranks as a CHILD job -- torch.distributed.run,
+    one process per GPU -- before this process has touched a GPU, pass rank 0's JSON line on and return the child's exit code.
+    (Never exec: a process image must not be replaced on these hosts once a GPU is initialised, and this one stays to relay.)"""
+    import signal
+    import socket
+    import subprocess
+    import tempfile
+    import threading
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    fd, line_file = tempfile.mkstemp(prefix="bench_line_", suffix=".json")
+    os.close(fd)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs across processes on these hosts
+    env["FB_BENCH_LINE_FILE"] = line_file                      # rank 0 leaves the line here as soon as the headline run is done
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    timed_out = []
+
+    def end_child():
+        timed_out.append(True)
+        try:
+            os.killpg(child.pid, signal.SIGTERM)                # the exact process group started above
+            time.sleep(10)
+            os.killpg(child.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+    timer = threading.Timer(args.launch_timeout, end_child)
+    timer.daemon = True
+    timer.start()
+    line = None
+    for ln in child.stdout:
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                json.loads(t)
+                line = t
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(ln)
+    rc = child.wait()
+    timer.cancel()
+    if line is None:                                            # the job ended after the headline run but before its last line
+        try:
+            d = json.load(open(line_file))
+            d["incomplete"] = "the ranks ended (rc %d%s) after the headline run and before the final line; this is the line as of the headline run" % (
+                rc, ", launch timeout" if timed_out else "")
+            line = json.dumps(d)
+        except (OSError, ValueError):
+            pass
+    try:
+        os.remove(line_file)
+    except OSError:
+        pass
+    if line is not None:
+        print(line)
+    else:
+        sys.stderr.write("bench.py: the %d-rank job printed no line (rc %d)\n" % (args.gpus, rc))
+    return rc if rc else (0 if line is not None else 1)
+
+
+def workload_of(n, kind=None, source=None):
+    """BASELINE configs 2-5 by grid: (initial field, source-forced?, dt)."""
+    kind = kind or ("gaussian" if n == 8192 else ("kuo2004" if n >= 4096 else "elliptic"))
+    with_source = bool(source) if source is not None else n == 16384           # configs[4]: main-shallow-water.cpp path
+    return kind, with_source, (3.0 if n <= 1024 else 3.0 * 1024 / n)
+
+
+def workload_text(n, kind, with_source, dt):
+    return "%dx%d %s initial field%s, nu=6.5, L=600 km, dt=%.4g s, 4 RK stages/step, fused HIP path" % (
+        n, n, kind, ", source-forced (main-shallow-water.cpp path: vort_src = the FIFO producer's cake, in force every step)" if with_source else "", dt)
+
+
+def timed_steps(model, reset_state, K, W, spinup, barrier, sync):
+    """Spin-up (untimed, state restored), W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs: seconds."""
+    # Device spin-up (untimed, state restored afterwards): after >= 20 ms of idleness this GPU needs ~25 ms of
+    # *this* load to return to full speed (tools/step_trend.py: 1.31 -> 1.18 ms/step over the first 20 steps; a
+    # bandwidth-only torch kernel does not trigger it).  A short warm-up (W <= 10 steps) would otherwise be
+    # timed on that ramp.  The spin-up runs the workload itself and then resets the state, so the W warm-up
+    # steps and the K timed steps start from the initial condition as usual.
+    if spinup > 0:
+        model.step(spinup)
+        reset_state()
+    model.step(W)
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    model.step(K)
+    sync()
+    barrier()
+    sync()
+    return time.perf_counter() - t0
+
+
+def single_gpu_run(X, torch, n, kind, with_source, dt, K, W, spinup=None):
+    """One GPU, the fused model: (model, seconds for K steps, spin-up steps used)."""
+    model = X.Model(n, n, dt=dt)
+    v0 = torch.from_numpy(X.make_field(kind, n)).cuda()      # device copy: resetting the state does not idle the GPU
+    if with_source:                                          # vort_src as the FIFO producer hands it over (vort_src_input.cpp:35-46), in force for every step
+        model.set_source(X.make_source_kuo2004(n))
+    model.set_vort(v0)
+    if spinup is None:                                       # ~30 ms of work at the single-GPU rate of the grid
+        spinup = max(2, min(200, int(24 * (4096.0 / n) ** 2)))
+    elapsed = timed_steps(model, lambda: model.set_vort(v0), K, W, spinup, lambda: None, torch.cuda.synchronize)
+    return model, elapsed, spinup
+
+
+def slab_run(X, torch, dist, slab, args, n, kind, with_source, dt, rank, world):
+    """`world` ranks, the engine-driven slab model on grid n: dict of what the line reports about it (identical on every rank)."""
+    K, W = args.steps, args.warmup
+    dev = "cuda" if args.backend == "nccl" else "cpu"
+    # the engine-driven model: local passes, exchange buffers and the RCCL all-to-all transposes behind the C ABI
+    model = slab.SlabModel(n, n, dt=dt, rank=rank, world=world)
+    info = {"rows_per_rank": model.XL, "active_cols_per_rank": model.KA, "frozen_cols_per_rank": model.KF,
+            "field_groups": model.field_groups, "row_chunks": model.row_chunks, "col_groups": model.col_groups,
+            "transport": model.transport}
+    if args.backend == "nccl" and not model.transport.startswith("rccl (engine"):
+        raise SystemExit("bench.py: the multi-GPU line is only printed for the engine's RCCL transport, got %r" % model.transport)
+    # start-up check of the links before anything is timed: a known pattern through the transport, every word verified
+    wrong = model.transport_selftest()
+    tw = torch.tensor([wrong], device=dev, dtype=torch.int64)
+    dist.all_reduce(tw, op=dist.ReduceOp.SUM)
+    if int(tw.item()) != 0:
+        raise SystemExit("bench.py: the transport self-test found %d wrong words (rank %d: %d)" % (int(tw.item()), rank, wrong))
+    info["transport_selftest"] = "ok"
+    # what the communicator itself reports on every rank (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) and the HIP device ordinals
+    mine = model.transport_info()
+    mine["rank"] = rank
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    every.sort(key=lambda d: d["rank"])
+    counts = [d["comm_ranks"] for d in every]
+    rccl_ranks = counts[0] if (min(counts) == max(counts) and counts[0] > 0) else None
+    if args.backend == "nccl" and rccl_ranks != world:
+        raise SystemExit("bench.py: ncclCommCount reports %r on the ranks, expected %d everywhere" % (counts, world))
+    v0_local = torch.from_numpy(slab.local_rows(X.make_field(kind, n), rank, world)).cuda()
+    src_local = torch.from_numpy(slab.local_rows(X.make_source_kuo2004(n), rank, world)).cuda() if with_source else None
+    if with_source:
+        model.set_source_local(src_local)
+    model.set_vort_local(v0_local)
+    # spin-up for N > 1 as well (VERDICT r3): ~40 ms of this load at the rate the model of DESIGN.md section 6 predicts
+    pred_ms0, _ = slab.predicted_step_ms(n, n, world)
+    spinup = args.spinup_steps if args.spinup_steps is not None else max(2, min(100, int(40.0 / pred_ms0)))
+    elapsed = timed_steps(model, lambda: model.set_vort_local(v0_local), K, W, spinup, dist.barrier, torch.cuda.synchronize)
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    model.close()
+    # how much of that is local work: the same schedule with a transport that moves nothing (fields are garbage, timing is not)
+    m0 = slab.EngineSlab(n, n, dt=dt, rank=rank, world=world, transport="null", dist=dist)
+    m0.set_vort_local(v0_local)
+    if with_source:
+        m0.set_source_local(src_local)
+    m0.step(max(1, min(W, 3)))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    m0.step(K)
+    torch.cuda.synchronize()
+    tl = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+    dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+    local_ms = 1e3 * float(tl.item()) / K
+    m0.close()
+    del v0_local, src_local
+    pred_ms, terms = slab.predicted_step_ms(n, n, world, local_ms)
+    return {"steps_per_s": K / elapsed, "ms_per_step": 1e3 * elapsed / K, "spinup_steps": spinup, "slab": info,
+            "local_passes_ms_per_step": local_ms,          # the step with exchanges that move nothing: what is left is the links
+            "rccl_ranks": rccl_ranks, "devices": [d["hip_device"] for d in every],
+            "rccl": {"comm_ranks": counts, "comm_rank": [d["comm_rank"] for d in every], "comm_device": [d["comm_device"] for d in every]},
+            "predicted": dict({"steps_per_s": 1e3 / pred_ms, "what": "DESIGN.md section 6 model (slab.predicted_step_ms): stage = link time of "
+                               "5 fields x XL x KA complex per peer at an ASSUMED rate + the local work no transfer hides; not a measurement"},
+                              **terms)}
+
+
+def one_gpu_same_grid(X, torch, dist, args, n, kind, with_source, dt, rank):
+    """Rank 0 alone runs the single-GPU model on the same grid in the same job (the other ranks wait): steps/s, same on every rank."""
+    dev = "cuda" if args.backend == "nccl" else "cpu"
+    rate = 0.0
+    if rank == 0:
+        try:
+            model, elapsed, _ = single_gpu_run(X, torch, n, kind, with_source, dt, args.steps, args.warmup)
+            rate = args.steps / elapsed
+            del model
+            torch.cuda.empty_cache()
+        except Exception as e:                                   # reported, not fatal: the multi-GPU figure stands on its own
+            sys.stderr.write("bench.py: single-GPU run of %d^2 on rank 0 failed: %r\n" % (n, e))
+    t = torch.tensor([rate], device=dev, dtype=torch.float64)
+    dist.broadcast(t, src=0)
+    return float(t.item()) or None
+
+
+def driver_leg(X, n, kind, with_source, dt, steps, record_step=100):
+    """The drop-in C++ driver itself (host/barotropic_main.out: main.cpp:65-328 on the engine) on the same workload, BASELINE.md's stated run:
+    `steps` RK4 steps with a record every `record_step` (configuration.hpp:34-36), five record files per record step written by the
+    driver's writer thread into a temporary directory.  Parses the driver's own [timing] lines (stderr)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "xlab-fftbarotropic_amd", "host", "barotropic_main.out")
+    if not os.access(exe, os.X_OK):
+        return {"error": "host/barotropic_main.out is not built"}
+    d = tempfile.mkdtemp(prefix="bench_driver_")
+    try:
+        os.makedirs(os.path.join(d, "input"))
+        os.makedirs(os.path.join(d, "output"))
+        X.make_field(kind, n).tofile(os.path.join(d, "input", "initial_vorticity.bin"))
+        cmd = [exe, "--npts", str(n), "--dt", repr(dt), "--steps", str(steps), "--record-step", str(record_step)]
+        if with_source:
+            return {"error": "the driver leg runs the plain driver only (no FIFO producer is started here)"}
+        t0 = time.perf_counter()
+        res = subprocess.run(cmd, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if res.returncode != 0:
+            return {"error": "driver rc %d: %s" % (res.returncode, res.stderr[-300:])}
+        lines = [ln for ln in res.stderr.splitlines() if ln.startswith("[timing]")]
+        m1 = re.search(r"without the record steps ([0-9.]+) steps/s \(([0-9.]+) ms/step\) = ([0-9.]+) GB/s", lines[0]) if lines else None
+        m2 = re.search(r"with (\d+) record steps \(([0-9.]+) GB written[^)]*\): ([0-9.]+) steps/s over ([0-9.]+) s of wall time; the writer thread was busy "
+                       r"([0-9.]+) s = ([0-9.]+) GB/s", lines[1]) if len(lines) > 1 else None
+        if not (m1 and m2):
+            return {"error": "no [timing] lines from the driver", "stderr_tail": res.stderr[-300:]}
+        return {"program": "xlab-fftbarotropic_amd/host/barotropic_main.out " + " ".join(cmd[1:]),
+                "steps": steps, "record_step": record_step, "records": int(m2.group(1)),
+                "driver_steps_per_s": float(m1.group(1)),              # the step loop alone: GPU time between the record steps (events on the compute stream)
+                "driver_ms_per_step": float(m1.group(2)), "driver_achieved_hbm_GBs": float(m1.group(3)),
+                "driver_wall_steps_per_s": float(m2.group(3)),         # host clock around the loop, writer thread and its files included
+                "driver_wall_s": float(m2.group(4)), "record_GB_written": float(m2.group(2)),
+                "writer_busy_s": float(m2.group(5)), "writer_disk_GBs": float(m2.group(6)),
+                "process_wall_s": wall,                                # start-up (context, tables, pitch probe), input read and teardown included
+                "timing_lines": lines}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # before any GPU call and before torch is imported: the ranks are a child job
+        raise SystemExit(self_launch(args))
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or from a plain shell, "
+                         "which starts the ranks itself)" % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))     # rehearsal on one GPU: ranks share it
 
     import xlab_fftbarotropic_amd as X
     n = args.n
-    kind = args.kind or ("gaussian" if n == 8192 else ("kuo2004" if n >= 4096 else "elliptic"))      # BASELINE configs 2-5
-    with_source = bool(args.source) if args.source is not None else n == 16384                         # configs[4]: main-shallow-water.cpp path
-    dt = 3.0 if n <= 1024 else 3.0 * 1024 / n
+    kind, with_source, dt = workload_of(n, args.kind, args.source)
     K, W = args.steps, args.warmup
-    slab_info = None
+    alg_bytes = 320.0 * n * n
+
+    def base_line(steps_per_s, ms_per_step, spinup):
+        return {
+            "metric": "RK4 steps/sec, %dx%d periodic grid" % (n, n), "value": steps_per_s, "unit": "steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "spinup_steps": spinup,
+            "config": {"workload": workload_text(n, kind, with_source, dt),
+                       "grid": [n, n], "source": with_source, "parallelism": "slab%d" % world if world > 1 else "single"},
+            "achieved_hbm_GBs": alg_bytes * steps_per_s / 1e9,
+            "step_roofline_frac": alg_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBS * world),
+            "tight_frac": 256.0 * n * n * steps_per_s / 1e9 / (HBM_PEAK_GBS * world),
+        }
 
     if world > 1:
         import torch.distributed as dist
@@ -178,139 +439,83 @@ def main():
             dist.init_process_group(args.backend)
         from importlib import import_module
         slab = import_module("xlab-fftbarotropic_amd.slab")
-        # the engine-driven model: local passes, exchange buffers and the RCCL all-to-all transposes behind the C ABI
-        model = slab.SlabModel(n, n, dt=dt, rank=rank, world=world)
-        slab_info = {"rows_per_rank": model.XL, "active_cols_per_rank": model.KA, "frozen_cols_per_rank": model.KF,
-                     "field_groups": model.field_groups, "row_chunks": model.row_chunks, "col_groups": model.col_groups,
-                     "transport": model.transport}
-        if args.backend == "nccl" and not model.transport.startswith("rccl (engine"):
-            raise SystemExit("bench.py: the multi-GPU line is only printed for the engine's RCCL transport, got %r" % model.transport)
-        # start-up check of the links before anything is timed: a known pattern through the transport, every word verified
-        wrong = model.transport_selftest()
-        tw = torch.tensor([wrong], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.int64)
-        dist.all_reduce(tw, op=dist.ReduceOp.SUM)
-        if int(tw.item()) != 0:
-            raise SystemExit("bench.py: the transport self-test found %d wrong words (rank %d: %d)" % (int(tw.item()), rank, wrong))
-        slab_info["transport_selftest"] = "ok"
-        v0_local = torch.from_numpy(slab.local_rows(X.make_field(kind, n), rank, world)).cuda()
-        if with_source:
-            model.set_source_local(torch.from_numpy(slab.local_rows(X.make_source_kuo2004(n), rank, world)).cuda())
-
-        def reset_state():
-            model.set_vort_local(v0_local)
-        reset_state()
-        barrier = dist.barrier
-    else:
-        model = X.Model(n, n, dt=dt)
-        v0 = torch.from_numpy(X.make_field(kind, n)).cuda()      # device copy: resetting the state does not idle the GPU
-        if with_source:                                          # vort_src as the FIFO producer hands it over (vort_src_input.cpp:35-46), in force for every step
-            model.set_source(X.make_source_kuo2004(n))
-
-        def reset_state():
-            model.set_vort(v0)
-        reset_state()
-
-        def barrier():
-            return None
-    if args.spinup_steps is None:                   # ~30 ms of work at the single-GPU rate of the grid
-        args.spinup_steps = 0 if world > 1 else max(2, min(200, int(24 * (4096.0 / n) ** 2)))
-
-    # Device spin-up (untimed, state restored afterwards): after >= 20 ms of idleness this GPU needs ~25 ms of
-    # *this* load to return to full speed (tools/step_trend.py: 1.31 -> 1.18 ms/step over the first 20 steps; a
-    # bandwidth-only torch kernel does not trigger it).  A short warm-up (W <= 10 steps) would otherwise be
-    # timed on that ramp.  The spin-up runs the workload itself and then resets the state, so the W warm-up
-    # steps and the K timed steps start from the initial condition as usual.
-    if args.spinup_steps > 0:
-        model.step(args.spinup_steps)
-        reset_state()
-    model.step(W)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    model.step(K)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    local_ms = None
-    if world > 1:
-        # how much of that is local work: the same schedule with a transport that moves nothing (fields are garbage, timing is not)
-        m0 = slab.EngineSlab(n, n, dt=dt, rank=rank, world=world, transport="null", dist=dist)
-        m0.set_vort_local(v0_local)
-        if with_source:
-            m0.set_source_local(torch.from_numpy(slab.local_rows(X.make_source_kuo2004(n), rank, world)).cuda())
-        m0.step(max(1, min(W, 3)))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        m0.step(K)
-        torch.cuda.synchronize()
-        tl = torch.tensor([time.perf_counter() - t1], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
-        local_ms = 1e3 * float(tl.item()) / K
-        m0.close()
-
-    ms_per_step = 1e3 * elapsed / K
-    steps_per_s = K / elapsed
-    alg_bytes = 320.0 * n * n
-    out = {
-        "metric": "RK4 steps/sec, %dx%d periodic grid" % (n, n), "value": steps_per_s, "unit": "steps/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "spinup_steps": args.spinup_steps,
-        "config": {"workload": "%dx%d %s initial field%s, nu=6.5, L=600 km, dt=%.4g s, 4 RK stages/step, fused HIP path"
-                               % (n, n, kind, ", source-forced (main-shallow-water.cpp path: vort_src = the FIFO producer's cake, in force every step)"
-                                  if with_source else "", dt),
-                   "grid": [n, n], "source": with_source, "parallelism": "slab%d" % world if world > 1 else "single"},
-        "achieved_hbm_GBs": alg_bytes * steps_per_s / 1e9,
-        "step_roofline_frac": alg_bytes * steps_per_s / 1e9 / (HBM_PEAK_GBS * world),
-        "tight_frac": 256.0 * n * n * steps_per_s / 1e9 / (HBM_PEAK_GBS * world),
-    }
-    if slab_info:
-        out["config"]["slab"] = slab_info
-        out["local_passes_ms_per_step"] = local_ms          # the step with exchanges that move nothing: what is left is the links
-
-    if rank == 0 and world == 1:
-        # per-kernel HIP-event timing over a second pass of the same K steps (events on the launch stream)
-        prof = model.profile_steps(K)
-        torch.cuda.synchronize()
-        if prof["k_col_strided_bwd4"][1] == 0 and prof["k_col_strided_fwd1"][1] == 0:     # single-pass x transform in use
-            prof = {"k_row_fused": prof["k_row_fused"], "k_col_full": prof["k_col_mid"]}
-        per = {k: (ms / max(cnt, 1)) for k, (ms, cnt) in prof.items()}
-        tot = {k: ms for k, (ms, cnt) in prof.items()}
-        dom = max(tot, key=tot.get)
-        pmc_path, pmc = pmc_profile(n)
-        traffic = {k: pmc_traffic(pmc, k) for k in per}
-        ach = ALG_N2[dom] * n * n / (per[dom] * 1e-3) / 1e9
-        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic[dom],
-                           "traffic_frac": (traffic[dom] / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic[dom] else None,
-                           # provenance of `traffic`: NOT measured by this run (PMC passes need their own rocprofv3 runs)
-                           "traffic_source": ({"file": pmc_path, "commit": pmc.get("commit"), "command": pmc.get("command")} if pmc else None),
-                           "avg_launch_ms": per[dom], "alg_bytes_per_launch": ALG_N2[dom] * n * n}
-        out["kernels_ms_per_launch"] = per
-        out["kernels_ms_per_step"] = {k: v / K for k, v in tot.items()}
-        # credit-based and counter-based rates side by side: the contract's 8 N^2-per-pass credit counts the row pass's
-        # traffic twice (it reads 4 C and writes 1 C for 40 N^2 of credit), the counter bytes are what really crosses the fabric
-        out["kernels_GBs"] = {k: {"credit": ALG_N2[k] * n * n / (per[k] * 1e-3) / 1e9,
-                                  "traffic": (traffic[k] / (per[k] * 1e-3) / 1e9) if traffic[k] else None} for k in per}
-        if all(traffic.values()):
-            per_step = sum(traffic[k] * (prof[k][1] / K) for k in per)
-            out["traffic_bytes_per_step"] = per_step
-            out["traffic_frac"] = per_step * steps_per_s / 1e9 / HBM_PEAK_GBS
-        if args.cpu_steps > 0:
-            out["cpu_baseline"] = cpu_baseline(n, dt, kind, args.cpu_steps, with_source)
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
-        model.close()
+        r = slab_run(X, torch, dist, slab, args, n, kind, with_source, dt, rank, world)
+        out = base_line(r["steps_per_s"], r["ms_per_step"], r["spinup_steps"])
+        out["config"]["slab"] = r["slab"]
+        for k in ("local_passes_ms_per_step", "rccl_ranks", "devices", "rccl", "predicted"):
+            out[k] = r[k]
+        leave = os.environ.get("FB_BENCH_LINE_FILE")
+        if rank == 0 and leave:                                  # a later failure must not cost the headline figure (self_launch reads this)
+            with open(leave, "w") as f:
+                json.dump(out, f)
+        one = one_gpu_same_grid(X, torch, dist, args, n, kind, with_source, dt, rank)
+        out["one_gpu_same_grid_steps_per_s"] = one               # rank 0 alone, the fused single-GPU model, same grid, same job
+        out["vs_1gpu_same_grid"] = (r["steps_per_s"] / one) if one else None
+        # the workloads BASELINE names for this many GPUs, in the same job: configs[3] at N = 4, configs[4] at N = 8
+        also = {"auto": {4: [8192], 8: [16384]}.get(world, []), "none": []}.get(args.also_grid)
+        if also is None:
+            also = [int(g) for g in args.also_grid.split(",") if g]
+        out["configs_run"] = []
+        for g in also:
+            gk, gs, gdt = workload_of(g)
+            rg = slab_run(X, torch, dist, slab, args, g, gk, gs, gdt, rank, world)
+            og = one_gpu_same_grid(X, torch, dist, args, g, gk, gs, gdt, rank)
+            out["configs_run"].append({
+                "workload": workload_text(g, gk, gs, gdt), "grid": [g, g], "source": gs, "value": rg["steps_per_s"], "unit": "steps/s",
+                "ms_per_step": rg["ms_per_step"], "steps": K, "warmup": W, "spinup_steps": rg["spinup_steps"],
+                "local_passes_ms_per_step": rg["local_passes_ms_per_step"], "predicted": rg["predicted"], "slab": rg["slab"],
+                "rccl_ranks": rg["rccl_ranks"], "one_gpu_same_grid_steps_per_s": og, "vs_1gpu_same_grid": (rg["steps_per_s"] / og) if og else None,
+                "step_roofline_frac": 320.0 * g * g * rg["steps_per_s"] / 1e9 / (HBM_PEAK_GBS * world)})
+            if rank == 0 and leave:
+                with open(leave, "w") as f:
+                    json.dump(out, f)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        dist.barrier()
         dist.destroy_process_group()
+        return
+
+    model, elapsed, spinup = single_gpu_run(X, torch, n, kind, with_source, dt, K, W, args.spinup_steps)
+    out = base_line(K / elapsed, 1e3 * elapsed / K, spinup)
+    steps_per_s = K / elapsed
+
+    # per-kernel HIP-event timing over a second pass of the same K steps (events on the launch stream)
+    prof = model.profile_steps(K)
+    torch.cuda.synchronize()
+    if prof["k_col_strided_bwd4"][1] == 0 and prof["k_col_strided_fwd1"][1] == 0:     # single-pass x transform in use
+        prof = {"k_row_fused": prof["k_row_fused"], "k_col_full": prof["k_col_mid"]}
+    per = {k: (ms / max(cnt, 1)) for k, (ms, cnt) in prof.items()}
+    tot = {k: ms for k, (ms, cnt) in prof.items()}
+    dom = max(tot, key=tot.get)
+    pmc_path, pmc = pmc_profile(n)
+    traffic = {k: pmc_traffic(pmc, k) for k in per}
+    ach = ALG_N2[dom] * n * n / (per[dom] * 1e-3) / 1e9
+    out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": ach / HBM_PEAK_GBS, "traffic": traffic[dom],
+                       "traffic_frac": (traffic[dom] / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic[dom] else None,
+                       # provenance of `traffic`: NOT measured by this run (PMC passes need their own rocprofv3 runs)
+                       "traffic_source": ({"file": pmc_path, "commit": pmc.get("commit"), "command": pmc.get("command")} if pmc else None),
+                       "avg_launch_ms": per[dom], "alg_bytes_per_launch": ALG_N2[dom] * n * n}
+    out["kernels_ms_per_launch"] = per
+    out["kernels_ms_per_step"] = {k: v / K for k, v in tot.items()}
+    # credit-based and counter-based rates side by side: the contract's 8 N^2-per-pass credit counts the row pass's
+    # traffic twice (it reads 4 C and writes 1 C for 40 N^2 of credit), the counter bytes are what really crosses the fabric
+    out["kernels_GBs"] = {k: {"credit": ALG_N2[k] * n * n / (per[k] * 1e-3) / 1e9,
+                              "traffic": (traffic[k] / (per[k] * 1e-3) / 1e9) if traffic[k] else None} for k in per}
+    if all(traffic.values()):
+        per_step = sum(traffic[k] * (prof[k][1] / K) for k in per)
+        out["traffic_bytes_per_step"] = per_step
+        out["traffic_frac"] = per_step * steps_per_s / 1e9 / HBM_PEAK_GBS
+    del model
+    torch.cuda.empty_cache()
+    dsteps = args.driver_steps if args.driver_steps is not None else (1000 if (n == 4096 and not with_source) else 0)
+    if dsteps > 0:
+        out["driver"] = driver_leg(X, n, kind, with_source, dt, dsteps)
+        if "driver_steps_per_s" in out["driver"]:
+            out["driver"]["vs_value"] = out["driver"]["driver_steps_per_s"] / steps_per_s
+    if args.cpu_steps > 0:
+        out["cpu_baseline"] = cpu_baseline(n, dt, kind, args.cpu_steps, with_source)
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -83,6 +83,10 @@ int fb_event_destroy(void *event);
 int fb_event_record(void *event, void *stream);
 int fb_stream_wait_event(void *stream, void *event);
 int fb_event_synchronize(void *event);
+/* events that carry a time stamp, and the GPU time between two of them once both have fired: how the drop-in driver prices its
+ * step loop (steps/s without the record steps' stalls) without synchronising it */
+int fb_event_create_timing(void **event);
+int fb_event_elapsed_ms(void *start, void *stop, float *ms);
 int fb_memcpy_d2h_async(void *stream, void *h_dst, const void *d_src, size_t bytes);
 /* the other direction, for the FIFO source (main-shallow-water.cpp:304: a reader thread fills a pinned buffer, the copy
  * stream carries it to the device, the compute stream waits for the copy's event before fb_model_set_source) */
@@ -211,6 +215,10 @@ int fb_slab_wait_event(fb_slab *s, void *event);
 int fb_slab_time_steps(fb_slab *s, int nsteps, float *total_ms);
 /* exchanges a known pattern of world*count floats through the connected transport; *wrong_words = 0 when every word arrived */
 int fb_slab_transport_selftest(fb_slab *s, size_t count, size_t *wrong_words);
+/* what is connected: transport name ("rccl", "local", "callback", "none" for world == 1), the size / rank / device of the transport's
+ * own communicator (RCCL: ncclCommCount, ncclCommUserRank, ncclCommCuDevice; -1 where the transport has none) and this rank's HIP
+ * device ordinal.  Any pointer may be NULL. */
+int fb_slab_transport_info(fb_slab *s, char *name, size_t cap, int *comm_ranks, int *comm_rank, int *comm_device, int *hip_device);
 int fb_slab_info(fb_slab *s, int *rows_local, int *cols_active, int *cols_frozen, int *ky0_active, int *ky0_frozen,
                  int *field_groups, int *row_chunks);
 /* host logic, no GPU needed: XL, KA, KF of a decomposition */

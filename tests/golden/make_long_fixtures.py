@@ -83,6 +83,55 @@ def oracle8192():
     print("done in %.0f s" % (time.time() - t0))
 
 
+def oracle8192_1000():
+    """configs[3] to the north-star horizon: steps 10 / 100 / 300 / 600 / 1000."""
+    import oracle_py as O
+    n, dt, sub = 8192, 0.375, 32
+    m = O.Model(n, n, dt=dt)
+    m.set_vort(O.make_field("gaussian", n))
+    out = {"note": np.array("oracle/liboracle.so, 8192^2 gaussian (makefield-gaussian.cpp:14-31), nu=6.5, L=600 km, dt=0.375 s; "
+                            "vort[::32, ::32], full-field l2 = sqrt(sum(vort^2)) in float64; made by "
+                            "tests/golden/make_long_fixtures.py oracle8192_1000")}
+    done, t0 = 0, time.time()
+    for upto in (10, 100, 300, 600, 1000):
+        while done < upto:
+            m.step(10)
+            done += 10
+            print("step %d  %.0f s" % (done, time.time() - t0), flush=True)
+        _snap(out, str(upto), m.vort(), sub)
+        np.savez_compressed(os.path.join(HERE, "oracle_8192_step1000.npz"), **out)
+    print("done in %.0f s" % (time.time() - t0))
+
+
+def oracle16384_52():
+    """configs[4] over 52 steps across the source's on and off: the cake arrives before step 2 and the field of zeros before
+    step 27 (vort_src_input.cpp:40-55, shifted); records after steps 12, 26, 27, 40 and 52."""
+    import oracle_py as O
+    n, dt, sub, L = 16384, 0.1875, 64, 600000.0
+    on_step, off_step = 2, 27
+    m = O.Model(n, n, dt=dt)
+    m.set_vort(O.make_field("kuo2004", n))
+    out = {"note": np.array("oracle/liboracle.so, 16384^2 kuo2004 + source (main-shallow-water.cpp:277-338): cake 3e-3/10800 at "
+                            "(L/2+50 km, L/2), R=30 km handed over before step 2, zeros before step 27; nu=6.5, L=600 km, "
+                            "dt=0.1875 s; vort[::64, ::64]; made by tests/golden/make_long_fixtures.py oracle16384_52"),
+           "on_step": np.int64(on_step), "off_step": np.int64(off_step)}
+    t0 = time.time()
+    for step in range(1, 53):
+        if step == on_step:
+            src = np.zeros((n, n), dtype=np.float32)
+            O.add_cake(src, L, L, L / 2 + 50000.0, L / 2, 3e-3 / 10800.0, 30000.0)      # vort_src_input.cpp:46
+            m.set_source(src)
+            del src
+        elif step == off_step:
+            m.set_source(np.zeros((n, n), dtype=np.float32))                              # vort_src_input.cpp:52-55
+        m.step(1)
+        print("step %d  %.0f s" % (step, time.time() - t0), flush=True)
+        if step in (12, 26, 27, 40, 52):
+            _snap(out, str(step), m.vort(), sub)
+            np.savez_compressed(os.path.join(HERE, "oracle_16384_src_step52.npz"), **out)
+    print("done in %.0f s" % (time.time() - t0))
+
+
 def oracle16384():
     import oracle_py as O
     n, dt, sub, L = 16384, 0.1875, 64, 600000.0
@@ -130,4 +179,5 @@ def fp64_1024():
 
 
 if __name__ == "__main__":
-    {"oracle4096": oracle4096, "fp64_1024": fp64_1024, "oracle8192": oracle8192, "oracle16384": oracle16384}[sys.argv[1]]()
+    {"oracle4096": oracle4096, "fp64_1024": fp64_1024, "oracle8192": oracle8192, "oracle16384": oracle16384,
+     "oracle8192_1000": oracle8192_1000, "oracle16384_52": oracle16384_52}[sys.argv[1]]()

@@ -286,20 +286,48 @@ def _free_port():
     return p
 
 
+def _bench_line_checks(d):
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "slab2"
+    # what the line must carry for N > 1: the device ordinals, the model's prediction beside the value, rank 0's
+    # single-GPU rate on the same grid from the same job, a spin-up, and the further grids as configs_run
+    assert d["devices"] == [0, 0] and d["rccl_ranks"] is None                    # gloo rehearsal: no RCCL communicator to count
+    assert d["predicted"]["steps_per_s"] > 0 and d["predicted"]["local_from"].startswith("measured")
+    assert d["one_gpu_same_grid_steps_per_s"] > 0 and d["vs_1gpu_same_grid"] > 0 and d["spinup_steps"] >= 2
+    assert d["local_passes_ms_per_step"] > 0 and d["config"]["slab"]["transport_selftest"] == "ok"
+    (c,) = d["configs_run"]
+    assert c["grid"] == [256, 256] and c["value"] > 0 and c["one_gpu_same_grid_steps_per_s"] > 0 and c["predicted"]["steps_per_s"] > 0
+
+
 def test_bench_two_ranks_on_one_gpu_gloo(tmp_path):
     """The real multi-process flow of bench.py (torch.distributed.run, one EngineSlab per process, the callback transport
-    over gloo) with 2 ranks sharing the GPU -- RCCL itself needs two devices."""
+    over gloo) with 2 ranks sharing the GPU -- RCCL itself needs two devices.  Launched the way the contract documents for N > 1."""
     import json
     import subprocess
     import sys
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--grid", "512", "--backend", "gloo", "--cpu-steps", "0"]
+           "--grid", "512", "--backend", "gloo", "--cpu-steps", "0", "--also-grid", "256"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
-    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "slab2"
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                                       # ONE JSON line
+    _bench_line_checks(json.loads(lines[0]))
+
+
+def test_bench_starts_its_own_ranks_from_a_plain_shell(tmp_path):
+    """`python bench.py --gpus 2 ...` with no launcher around it (the form of the driver's BENCH command): the parent starts the
+    ranks as a child torch.distributed.run job before it has touched a GPU, relays rank 0's line and returns the child's code."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--grid", "512", "--steps", "3", "--warmup", "1",
+           "--cpu-steps", "0", "--also-grid", "256"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{")                         # stdout is the line and nothing else
+    _bench_line_checks(json.loads(lines[0]))
 
 
 def test_engine_slab_two_processes_gloo_matches_single(tmp_path):

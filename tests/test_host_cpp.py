@@ -21,7 +21,7 @@ def test_host_programs_link():
     import xlab_fftbarotropic_amd as X
     X.build_lib()
     _build()
-    for exe in ("barotropic_main.out", "shim_check.out", "invert_pres.out", "vort_src_input.out", "find_min.out", "fftw_shape_check.out",
+    for exe in ("barotropic_main.out", "shim_check.out", "invert_pres.out", "vort_src_input.out", "find_min.out", "makefield.out",
                 "comm_bootstrap_check.out"):
         assert os.access(os.path.join(HOST, exe), os.X_OK)
 
@@ -352,36 +352,92 @@ def test_fifo_producer_under_asan():
     assert len(raw.stdout) == 11 + 2 * 64 * 64 * 4 and b"ERROR" not in raw.stderr and b"runtime error" not in raw.stderr
 
 
+def test_makefield_program_matches_the_reference_generators(tmp_path):
+    """host/makefield.out (fb_make_field + fb_write_field; makefield-elliptic-vortex.cpp:12-58, makefield-Kuo2004.cpp:30-41,
+    makefield-gaussian.cpp:14-31, makefield-const-vortex.cpp:14-38): at the reference's compiled-in NPTS = 768 the files carry the
+    hashes of the reference-built generators' output (tests/golden/ref_meta.json, made from oracle/_ref), both through --kind and
+    when started under the reference's program names; stderr is writeField's line (fieldio.cpp:18).  Host only (no GPU call).  Also
+    under AddressSanitizer + UBSan."""
+    import hashlib
+    import json
+    import xlab_fftbarotropic_amd as X
+    X.build_lib()
+    _build()
+    subprocess.check_call(["make", "-s", "-C", HOST, "asan"])
+    meta = json.load(open(os.path.join(HERE, "golden", "ref_meta.json")))
+    (tmp_path / "input").mkdir()
+    (tmp_path / "alt").mkdir()
+    names = {"elliptic": "makefield-elliptic-vortex.out", "kuo2004": "makefield-Kuo2004.out", "gaussian": "makefield-gaussian.out",
+             "const": "makefield-const-vortex.out"}
+    for kind, prog in names.items():
+        res = subprocess.run([os.path.join(HOST, "makefield.out"), "--kind", kind], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, check=True)
+        assert res.stderr == "Output input/initial_vorticity.bin\n" and res.stdout == ""
+        raw = (tmp_path / "input" / "initial_vorticity.bin").read_bytes()
+        assert len(raw) == meta[kind]["nbytes"] and hashlib.sha256(raw).hexdigest() == meta[kind]["sha256"], kind
+        link = tmp_path / prog                                                    # the reference's program name, no arguments
+        os.symlink(os.path.join(HOST, "makefield.out"), str(link))
+        subprocess.run([str(link), "-I", "alt", "-i", "f.bin"], cwd=str(tmp_path), stderr=subprocess.DEVNULL, check=True)
+        assert (tmp_path / "alt" / "f.bin").read_bytes() == raw
+        if os.path.exists(os.path.join(REFDIR, prog)):                            # build container: the reference's own program, side by side
+            (tmp_path / "ref" / "input").mkdir(parents=True, exist_ok=True)
+            subprocess.run([os.path.join(REFDIR, prog)], cwd=str(tmp_path / "ref"), stderr=subprocess.DEVNULL, check=True)
+            assert (tmp_path / "ref" / "input" / "initial_vorticity.bin").read_bytes() == raw
+    san = subprocess.run([os.path.join(HOST, "asan", "makefield.out"), "--kind", "kuo2004", "--npts", "192", "-I", "alt", "-i", "s.bin"],
+                         cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
+    assert "ERROR" not in san.stderr and "runtime error" not in san.stderr
+    small = subprocess.run([os.path.join(HOST, "makefield.out"), "--kind", "kuo2004", "--npts", "192", "-I", "alt", "-i", "t.bin"],
+                           cwd=str(tmp_path), stderr=subprocess.DEVNULL)
+    assert small.returncode == 0 and (tmp_path / "alt" / "s.bin").read_bytes() == (tmp_path / "alt" / "t.bin").read_bytes()
+    assert subprocess.run([os.path.join(HOST, "makefield.out")], cwd=str(tmp_path), stderr=subprocess.DEVNULL).returncode == 2
+    assert subprocess.run([os.path.join(HOST, "makefield.out"), "--kind", "nope"], cwd=str(tmp_path), stderr=subprocess.DEVNULL).returncode == 1
+
+
 @pytest.mark.gpu
-def test_fftw_shaped_translation_unit_matches_oracle(tmp_path):
-    """host/fftw_shape_check.cpp: the reference's call lines (#include <fftw3.h>, fftwf_malloc, fftwf_plan_dft_r2c_2d(XPTS, YPTS,
-    in, out, FFTW_ESTIMATE), fftwf_execute, readField/writeField, fop.gradx(...), host loops) linked against
-    -lfftw3f_fb -lfieldio: rk1_c of main.cpp:146-244,296 against the oracle."""
+def test_runtest_example_on_product_binaries_only(tmp_path):
+    """test/01-runtest/example.sh:3-10 with nothing but product binaries: `mkdir input output`, the generator under the reference's
+    program name (a link to host/makefield.out), then the driver with no arguments (NPTS = 768, dt = 3 s, 1200 steps, a record every 100:
+    configuration.hpp:18,34-36).  Checked: the step lines and ./log as main.cpp:262-264,266-282 writes them, the records against the oracle
+    at steps 0 and 100, and the driver's [timing] summary on stderr (stdout carries none of it)."""
+    import re
     import oracle_py as O
     import ref_numpy as R
     _build()
-    n = 256
-    v0 = O.make_field("elliptic", n)
+    n = 768
     (tmp_path / "input").mkdir()
-    v0.tofile(str(tmp_path / "input" / "initial_vorticity.bin"))
-    out = str(tmp_path / "rk1.bin")
-    res = subprocess.run([os.path.join(HOST, "fftw_shape_check.out"), str(tmp_path / "input" / "initial_vorticity.bin"), out],
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, text=True)
-    assert "%d bytes read" % (n * n) in res.stderr and "Output %s" % out in res.stderr
-    got = np.fromfile(out, dtype="<f4")
-    ops = O.Operators(n, n, 6e5, 6e5)
-    vc = O.r2c(v0)
-    g = np.float32(n * n)
-    dzdx = O.c2r(ops.gradx(vc), n) / g
-    dzdy = O.c2r(ops.grady(vc), n) / g
-    psi = ops.invertLaplacian(vc)
-    u = -(O.c2r(ops.grady(psi), n) / g)
-    v = O.c2r(ops.gradx(psi), n) / g
-    t = -u * dzdx - v * dzdy
-    tc = O.r2c(t)
-    tc = (tc.view(np.float32) + ops.laplacian(vc).view(np.float32) * np.float32(6.5)).view(np.complex64)
-    want = ops.dealiase(tc).view(np.float32).ravel()
-    assert R.rel_l2(got, want) < 1e-5
+    (tmp_path / "output").mkdir()
+    os.symlink(os.path.join(HOST, "makefield.out"), str(tmp_path / "makefield-elliptic-vortex.out"))
+    subprocess.run([str(tmp_path / "makefield-elliptic-vortex.out")], cwd=str(tmp_path), stderr=subprocess.DEVNULL, check=True)
+    res = subprocess.run([os.path.join(HOST, "barotropic_main.out")], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    steps = [ln for ln in res.stdout.splitlines() if ln.startswith("# Step")]
+    assert len(steps) == 1200 and steps[100] == "# Step 100, time = 300.00, record now!" and steps[1199] == "# Step 1199, time = 3597.00"
+    assert "[timing]" not in res.stdout and res.stdout.splitlines()[-1] == "Program ends. Congrats!"
+    log = (tmp_path / "log").read_text().split()
+    assert len(log) == 12 * 5 and log[:2] == ["output/vort_src_input_step_0.bin", "output/vort_step_0.bin"]
+    tl = [ln for ln in res.stderr.splitlines() if ln.startswith("[timing]")]
+    assert len(tl) == 2
+    m1 = re.search(r"1200 RK4 steps, 768 x 768 grid, 1 GPU: step loop without the record steps ([0-9.]+) steps/s \(([0-9.]+) ms/step\) = ([0-9.]+) GB/s "
+                   r"by 320 N\^2 B/step = ([0-9.]+) of 8000 GB/s", tl[0])
+    m2 = re.search(r"with 12 record steps \(([0-9.]+) GB written\): ([0-9.]+) steps/s over ([0-9.]+) s of wall time", tl[1])
+    assert m1 and m2, tl
+    rate, wall_rate = float(m1.group(1)), float(m2.group(2))
+    assert rate > 0 and wall_rate > 0 and wall_rate <= rate * 1.02
+    assert abs(float(m1.group(3)) - 320.0 * n * n * rate / 1e9) <= 1.0 and abs(float(m2.group(1)) - 12 * 5 * n * n * 4 / 1e9) < 1e-3
+    v0 = np.fromfile(str(tmp_path / "input" / "initial_vorticity.bin"), dtype="<f4").reshape(n, n)
+    assert np.array_equal(v0, O.make_field("elliptic", n))
+    m = O.Model(n, n)
+    m.set_vort(v0)
+    rd = lambda name: np.fromfile(str(tmp_path / "output" / name), dtype="<f4").reshape(n, n)
+    for s_ in (0, 100):
+        psi, u, v = m.diag()
+        assert R.rel_l2(rd("vort_step_%d.bin" % s_), m.vort()) < 1e-5 and R.rel_l2(rd("psi_step_%d.bin" % s_), psi) < 1e-5
+        assert R.rel_l2(rd("u_step_%d.bin" % s_), u) < 1e-5 and R.rel_l2(rd("v_step_%d.bin" % s_), v) < 1e-5
+        m.step(100)
+    quiet = subprocess.run([os.path.join(HOST, "barotropic_main.out"), "--steps", "3", "--no-timing"], cwd=str(tmp_path), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.PIPE, text=True, check=True)
+    assert "[timing]" not in quiet.stderr
 
 
 @pytest.mark.gpu
@@ -563,9 +619,15 @@ def test_reference_pipeline_unmodified_runs_on_the_engine(tmp_path):
         d = tmp_path / tag
         (d / "input").mkdir(parents=True)
         (d / "output").mkdir()
-        subprocess.check_call([os.path.join(REFDIR, "makefield-Kuo2004.out")], cwd=str(d), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        # "ref": the reference's own programs throughout; "own": product binaries ONLY -- host/makefield.out under the
+        # reference's program name, host/vort_src_input.out, host/barotropic_main.out, host/invert_pres.out, host/find_min.out
+        if tag == "own":
+            os.symlink(os.path.join(HOST, "makefield.out"), str(d / "makefield-Kuo2004.out"))
+        subprocess.check_call([os.path.join(REFDIR, "makefield-Kuo2004.out") if tag == "ref" else str(d / "makefield-Kuo2004.out")], cwd=str(d),
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         os.mkfifo(str(d / "vort_src_fifo"))
-        prod = subprocess.Popen("%s > vort_src_fifo" % os.path.join(REFDIR, "vort_src_input.out"), shell=True, cwd=str(d), stderr=subprocess.DEVNULL)
+        prod = subprocess.Popen("%s > vort_src_fifo" % os.path.join(REFDIR if tag == "ref" else HOST, "vort_src_input.out"), shell=True, cwd=str(d),
+                                stderr=subprocess.DEVNULL)
         main = [os.path.join(LINKDIR, "main-shallow-water.out"), "-fvort_src_fifo"] if tag == "ref" else \
                [os.path.join(HOST, "barotropic_main.out"), "-fvort_src_fifo"]
         res = subprocess.run(main, cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
@@ -579,10 +641,11 @@ def test_reference_pipeline_unmodified_runs_on_the_engine(tmp_path):
         inv = [os.path.join(LINKDIR, "invert_pres.out")] if tag == "ref" else [os.path.join(HOST, "invert_pres.out")]
         subprocess.run(inv, cwd=str(d), input="\n".join(lines) + "\n", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, text=True, check=True, timeout=600)
         pres = sorted((f for f in os.listdir(str(d / "output")) if f.startswith("pres_step")), key=lambda f: int(re.findall(r"\d+", f)[0]))
-        fm = subprocess.run([os.path.join(REFDIR, "find_min.out")], cwd=str(d), input="".join("output/%s\n" % f for f in pres),
+        fm = subprocess.run([os.path.join(REFDIR if tag == "ref" else HOST, "find_min.out")], cwd=str(d), input="".join("output/%s\n" % f for f in pres),
                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, check=True)
         runs[tag] = (res.stdout, (d / "log").read_text(), fm.stdout, len(pres))
     steps_of = lambda out: [ln for ln in out.splitlines() if ln.startswith("# Step")]
+    assert (tmp_path / "ref" / "input" / "initial_vorticity.bin").read_bytes() == (tmp_path / "own" / "input" / "initial_vorticity.bin").read_bytes()
     assert steps_of(runs["ref"][0]) == steps_of(runs["own"][0]) and len(steps_of(runs["ref"][0])) == 1200
     # the reference's plain driver main.cpp (no source path, rk4_c / dvortdt_c buffers: main.cpp:286-317), unmodified, on the same input
     d = tmp_path / "ref_main"

@@ -197,3 +197,46 @@ def test_rccl_connect_outcome_is_collective(tmp_path, fail_rank, fail_step):
             assert got[r][0] == "connected", got
         else:
             assert got[r][0].startswith("raised"), got
+
+
+def test_predicted_step_model_reproduces_the_design_table():
+    """slab.predicted_step_ms is DESIGN.md section 6's model as numbers (what bench.py prints as `predicted` beside a multi-GPU
+    `value`): link time of 5 fields x XL x KA complex per peer at the assumed rate + the local work no transfer hides.  Host logic."""
+    from importlib import import_module
+    slab = import_module("xlab-fftbarotropic_amd.slab")
+    # per peer and stage 80 MB at 4096^2 / 2, 8192^2 / 4 and 16384^2 / 8 (DESIGN.md section 6): 1.33 ms at 60 GB/s + 2 group latencies
+    for n, world in ((4096, 2), (8192, 4), (16384, 8)):
+        _, t = slab.predicted_step_ms(n, n, world, 1.0)
+        xl, ka, _kf = slab.slab_geometry(n, n, world)
+        assert abs(t["t_link_ms_per_stage"] - (5 * xl * ka * 8 / 60e9 * 1e3 + 0.06)) < 1e-9 and 1.3 < t["t_link_ms_per_stage"] < 1.5
+    # the measured rank-local step times of DESIGN.md section 6 give the table's rates
+    for n, world, local, lo, hi in ((4096, 2, 0.85, 150, 200), (4096, 4, 0.33, 450, 700), (4096, 8, 0.23, 1000, 1400),
+                                    (8192, 4, 1.47, 150, 190), (16384, 8, 3.11, 150, 190)):
+        ms, t = slab.predicted_step_ms(n, n, world, local)
+        assert lo < 1e3 / ms < hi, (n, world, 1e3 / ms)
+        assert t["exposed_ms_per_stage"] <= t["local_ms_per_stage"] + 1e-12 and t["local_from"].startswith("measured")
+    # nothing pipelined (one field group, one row chunk, one column group): everything local is exposed
+    _, t = slab.predicted_step_ms(4096, 4096, 8, 0.23)
+    assert abs(t["exposed_ms_per_stage"] - t["local_ms_per_stage"]) < 1e-12
+    ms1, t1 = slab.predicted_step_ms(4096, 4096, 1)
+    assert t1["t_link_ms"] == 0.0 and ms1 > 0
+    # without a measurement the local passes are priced at 22.4 C / world at 5 TB/s
+    _, t = slab.predicted_step_ms(8192, 8192, 4)
+    assert t["local_from"].startswith("22.4 C") and 0.2 < t["local_ms_per_stage"] < 0.4
+
+
+def test_bench_parent_reports_a_failed_child_job(tmp_path):
+    """`python bench.py --gpus 2` from a plain shell starts its ranks as a child job (bench.self_launch).  Here there is no GPU, so the
+    ranks fail at start-up: the parent must come back with a non-zero code, an empty stdout (no half line) and the reason on stderr --
+    not hang, and not exec anything."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the GPU suite runs the working launch")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--grid", "256", "--steps", "1",
+                          "--warmup", "0", "--cpu-steps", "0", "--launch-timeout", "240"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=400, env=env, cwd=str(tmp_path))
+    assert res.returncode != 0 and res.stdout.strip() == ""
+    assert "printed no line" in res.stderr
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os.exec" not in src and "execv" not in src

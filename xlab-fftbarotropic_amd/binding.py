@@ -104,6 +104,7 @@ def lib():
     L.fb_slab_time_steps.argtypes = [vp, ip, C.POINTER(C.c_float)]
     L.fb_slab_transport_selftest.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.fb_slab_info.argtypes = [vp] + [C.POINTER(ip)] * 7
+    L.fb_slab_transport_info.argtypes = [vp, C.c_char_p, C.c_size_t] + [C.POINTER(ip)] * 4
     L.fb_slab_geometry.argtypes = [ip, ip, ip] + [C.POINTER(ip)] * 3
     L.fb_slab_plan.argtypes = [ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip), ip]
     L.fb_write_field.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t]
@@ -122,8 +123,8 @@ EXPORTS = [
     "fb_model_time_steps", "fb_model_profile_steps", "fb_write_field", "fb_read_field", "fb_make_field", "fb_make_source_kuo2004",
     "fb_create_slab", "fb_slab_unique_id", "fb_slab_create", "fb_slab_destroy", "fb_slab_connect_rccl", "fb_local_hub_create",
     "fb_local_hub_destroy", "fb_slab_connect_local", "fb_slab_connect_callback", "fb_slab_set_vort_local", "fb_slab_set_source_local",
-    "fb_slab_get_vort_local", "fb_slab_get_diag_local", "fb_slab_step", "fb_slab_synchronize", "fb_slab_time_steps", "fb_slab_transport_selftest", "fb_slab_info", "fb_slab_geometry", "fb_slab_plan", "fb_slab_col_groups",
-    "fb_malloc_host", "fb_free_host", "fb_stream_create", "fb_stream_destroy", "fb_stream_synchronize", "fb_event_create",
+    "fb_slab_get_vort_local", "fb_slab_get_diag_local", "fb_slab_step", "fb_slab_synchronize", "fb_slab_time_steps", "fb_slab_transport_selftest", "fb_slab_transport_info", "fb_slab_info", "fb_slab_geometry", "fb_slab_plan", "fb_slab_col_groups",
+    "fb_malloc_host", "fb_free_host", "fb_stream_create", "fb_stream_destroy", "fb_stream_synchronize", "fb_event_create", "fb_event_create_timing", "fb_event_elapsed_ms",
     "fb_event_destroy", "fb_event_record", "fb_stream_wait_event", "fb_event_synchronize", "fb_memcpy_d2h_async", "fb_memcpy_h2d_async", "fb_slab_record_event", "fb_slab_wait_event",
 ]
 

@@ -41,6 +41,9 @@ struct RcclApi {
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     const char *(*GetErrorString)(ncclResult_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);          // the three below: optional (reporting only)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *);
 };
 RcclApi g_rccl;
 std::mutex g_rccl_mu;
@@ -61,6 +64,9 @@ int rccl_load()
     SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+    *(void **)(&a.CommCount) = dlsym(h, "ncclCommCount");
+    *(void **)(&a.CommUserRank) = dlsym(h, "ncclCommUserRank");
+    *(void **)(&a.CommCuDevice) = dlsym(h, "ncclCommCuDevice");
     g_rccl = a;
     return FB_OK;
 }
@@ -95,6 +101,16 @@ int rccl_alltoall(void *self, const float *send, float *recv, size_t stride, siz
                               hipMemcpyDeviceToDevice, stream));
     return FB_OK;
 }
+// what the communicator itself says it is: the proof, on a bench line, that RCCL connected `world` ranks (not a name string)
+int rccl_info(void *self, int *comm_ranks, int *comm_rank, int *device)
+{
+    RcclTransport *t = (RcclTransport *)self;
+    int v = -1;
+    if (comm_ranks) { *comm_ranks = -1; if (g_rccl.CommCount && g_rccl.CommCount(t->comm, &v) == ncclSuccess) *comm_ranks = v; }
+    if (comm_rank) { *comm_rank = -1; if (g_rccl.CommUserRank && g_rccl.CommUserRank(t->comm, &v) == ncclSuccess) *comm_rank = v; }
+    if (device) { *device = -1; if (g_rccl.CommCuDevice && g_rccl.CommCuDevice(t->comm, &v) == ncclSuccess) *device = v; }
+    return FB_OK;
+}
 void rccl_destroy(void *self)
 {
     RcclTransport *t = (RcclTransport *)self;
@@ -125,6 +141,7 @@ int fb_transport_rccl(fb_transport *tp, const char *unique_id, int rank, int wor
     ncclResult_t r = g_rccl.CommInitRank(&t->comm, world, id, rank);
     if (r != ncclSuccess) { delete t; return fail(FB_EHIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
     tp->self = t; tp->rank = rank; tp->world = world; tp->alltoall = rccl_alltoall; tp->destroy = rccl_destroy; tp->name = "rccl";
+    tp->info = rccl_info;
     return FB_OK;
 }
 

@@ -200,6 +200,21 @@ extern "C" int fb_slab_info(fb_slab *s, int *rows_local, int *cols_active, int *
     return FB_OK;
 }
 
+// What is connected: the transport's name, what ITS communicator reports (RCCL: ncclCommCount, ncclCommUserRank, ncclCommCuDevice;
+// -1 for transports without one) and the HIP device this rank computes on.
+extern "C" int fb_slab_transport_info(fb_slab *s, char *name, size_t cap, int *comm_ranks, int *comm_rank, int *comm_device, int *hip_device)
+{
+    if (!s) return fail(FB_EINVAL, "slab NULL");
+    const char *nm = s->c->world == 1 ? "none" : (s->connected && s->tp.name ? s->tp.name : "unconnected");
+    if (name && cap) { strncpy(name, nm, cap - 1); name[cap - 1] = 0; }
+    if (comm_ranks) *comm_ranks = -1;
+    if (comm_rank) *comm_rank = -1;
+    if (comm_device) *comm_device = -1;
+    if (s->connected && s->tp.info) s->tp.info(s->tp.self, comm_ranks, comm_rank, comm_device);
+    if (hip_device) { int d = -1; if (hipGetDevice(&d) != hipSuccess) d = -1; *hip_device = d; }
+    return FB_OK;
+}
+
 // Exchanges a known pattern through the connected transport (world*count floats each way) and returns the number of wrong
 // words: a start-up check of the links, and the one-GPU test of the RCCL call path (world = 1 with FB_RCCL_SELF=1).
 __global__ void k_slab_pattern(float *buf, size_t count, int world, int rank, int check, unsigned long long *bad)

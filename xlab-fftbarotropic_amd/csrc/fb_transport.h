@@ -18,6 +18,8 @@ struct fb_transport {
     int (*alltoall)(void *self, const float *send, float *recv, size_t stride, size_t offset, size_t count, hipStream_t stream);
     void (*destroy)(void *self);
     const char *name;
+    // optional: what the transport's own communicator reports (RCCL: ncclCommCount / ncclCommUserRank / ncclCommCuDevice), -1 where unknown
+    int (*info)(void *self, int *comm_ranks, int *comm_rank, int *device);
 };
 
 typedef int (*fb_alltoall_fn)(void *user, const float *send, float *recv, size_t stride, size_t offset, size_t count, void *hip_stream);

@@ -434,6 +434,21 @@ extern "C" int fb_event_create(void **ev)
     *ev = (void *)e;
     return FB_OK;
 }
+extern "C" int fb_event_create_timing(void **ev)
+{
+    if (!ev) return fail(FB_EINVAL, "fb_event_create_timing: NULL");
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    *ev = (void *)e;
+    return FB_OK;
+}
+extern "C" int fb_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    if (!start || !stop || !ms) return fail(FB_EINVAL, "fb_event_elapsed_ms: NULL");
+    HIPCHK(hipEventSynchronize((hipEvent_t)stop));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return FB_OK;
+}
 extern "C" int fb_event_destroy(void *ev) { if (ev) HIPCHK(hipEventDestroy((hipEvent_t)ev)); return FB_OK; }
 extern "C" int fb_event_record(void *ev, void *stream) { if (!ev) return fail(FB_EINVAL, "event NULL"); HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return FB_OK; }
 extern "C" int fb_stream_wait_event(void *stream, void *ev) { if (!ev) return fail(FB_EINVAL, "event NULL"); HIPCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0)); return FB_OK; }
@@ -1097,9 +1112,11 @@ extern "C" int fb_model_set_source(fb_model *m, const float *d_src)
     if (!m) return fail(FB_EINVAL, "model NULL");
     fb_ctx *c = m->c;
     const size_t n = (size_t)c->XL * c->ny * sizeof(float);       // the caller's local rows
+    // NULL: no source.  The row kernels test m->src alone, so the row flags (XL ints) are kept for the next source.
     if (!d_src) { if (m->src) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(m->src); m->src = nullptr; } return FB_OK; }
-    if (!m->src && hipMalloc((void **)&m->src, n) != hipSuccess) return fail(FB_ENOMEM, "source allocation failed");
-    if (!m->src_nz && hipMalloc((void **)&m->src_nz, (size_t)c->XL * sizeof(int)) != hipSuccess) return fail(FB_ENOMEM, "source allocation failed");
+    if (!m->src_nz && hipMalloc((void **)&m->src_nz, (size_t)c->XL * sizeof(int)) != hipSuccess) { m->src_nz = nullptr; return fail(FB_ENOMEM, "source allocation failed"); }
+    // the flags exist before the source is published: a model that goes on stepping after FB_ENOMEM never pairs a source with NULL flags
+    if (!m->src && hipMalloc((void **)&m->src, n) != hipSuccess) { m->src = nullptr; return fail(FB_ENOMEM, "source allocation failed"); }
     hipLaunchKernelGGL(k_src_row_flags, dim3(c->XL), dim3(256), 0, c->stream, d_src, m->src_nz, c->ny);
     HIPCHK(hipGetLastError());
     if (c->use_rowq) {                                            // k_rowq reads vort_src in its own physical-space order

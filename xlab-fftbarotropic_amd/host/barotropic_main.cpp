@@ -27,6 +27,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -54,6 +55,7 @@ struct Config {
     RECIPE_TYPE recipe_type = EMPTY;
     int world = 1, rank = 0; bool threads = false, fanout = false;
     long comm_max_age = 60, comm_timeout = 600;
+    bool timing = true;                                                            // the [timing] summary on stderr (--no-timing: off)
 };
 
 // --fifo-fanout (multi-GPU, SURVEY.md section 8(e) "rank 0 reads, scatters x-slabs"): ONE producer that writes whole fields -- the
@@ -64,23 +66,34 @@ static void fifo_fanout(const Config cfg)
 {
     const size_t slab = (size_t)(cfg.npts / cfg.world) * cfg.npts;
     FILE *in = fopen(cfg.vort_src_filename.c_str(), "rb");
-    if (!in) { printf("ERROR: cannot open file [%s].\n", cfg.vort_src_filename.c_str()); return; }
     std::vector<FILE *> out(cfg.world, nullptr);
-    for (int r = 0; r < cfg.world; ++r) {
+    bool opened = in != nullptr;
+    if (!in) printf("ERROR: cannot open file [%s].\n", cfg.vort_src_filename.c_str());
+    for (int r = 0; r < cfg.world && opened; ++r) {
         const std::string fn = cfg.vort_src_filename + "." + std::to_string(r);
-        if ((out[r] = fopen(fn.c_str(), "wb")) == NULL) { printf("ERROR: cannot open file [%s].\n", fn.c_str()); return; }
+        if ((out[r] = fopen(fn.c_str(), "wb")) == NULL) { printf("ERROR: cannot open file [%s].\n", fn.c_str()); opened = false; }
     }
-    std::vector<float> buf(slab);
+    if (!opened) {
+        // One FIFO of the fan-out is missing: the readers of those already opened get their EOF, and the launch ends here with a
+        // failure instead of leaving ranks inside fopen/fread for ever (the reference has ONE reader, vorticity_source.cpp:121-124,
+        // so it knows no such state).  _exit: this is a side thread of a process that is busy on the GPU.
+        for (FILE *f : out) if (f) fclose(f);
+        if (in) fclose(in);
+        fflush(stdout); fflush(stderr);
+        _exit(1);
+    }
+    std::vector<float> buf(slab * (size_t)cfg.world);
     char flag;
     while (fread(&flag, 1, 1, in) == 1) {
-        for (FILE *f : out) { fwrite(&flag, 1, 1, f); if (((unsigned int)flag) != 1) fflush(f); }
-        if (((unsigned int)flag) != 1) continue;
-        bool ok = true;
-        for (int r = 0; r < cfg.world && ok; ++r) {                                    // the field is x-major: rank r's rows are the r-th piece of the record
-            ok = fread(buf.data(), sizeof(float), slab, in) == slab;
-            if (ok) { fwrite(buf.data(), sizeof(float), slab, out[r]); fflush(out[r]); }
+        if (((unsigned int)flag) != 1) { for (FILE *f : out) { fwrite(&flag, 1, 1, f); fflush(f); } continue; }
+        // a record goes out only when ALL of it has arrived: a short one is passed on to no rank (every rank keeps the source it has,
+        // finds EOF and says so), never to some of them -- the ranks must not integrate different forcings
+        if (fread(buf.data(), sizeof(float), buf.size(), in) != buf.size()) { fprintf(stderr, "ERROR: Cannot read vorticity source input.\n"); fflush(stderr); break; }
+        for (int r = 0; r < cfg.world; ++r) {                                          // the field is x-major: rank r's rows are the r-th piece of the record
+            fwrite(&flag, 1, 1, out[r]);
+            fwrite(buf.data() + (size_t)r * slab, sizeof(float), slab, out[r]);
+            fflush(out[r]);
         }
-        if (!ok) break;                                                                // short record: the ranks report it as the reference does
     }
     for (FILE *f : out) fclose(f);                                                     // EOF for every rank ("No flag was detected")
     fclose(in);
@@ -183,6 +196,7 @@ struct RecordWriter {
     const float *src = nullptr; int src_buf = -1; SourceFeed *feed = nullptr;          // vort_src as of the record step
     std::string output; FILE *log_fd = nullptr; size_t floats = 0;
     bool whole = true, lead = true; off_t off = 0;                                     // whole file (writeField) or this rank's byte range
+    double busy_s = 0.0; size_t bytes = 0;                                             // time spent writing and what was written ([timing] summary)
     void start() { th = std::thread([this] { run(); }); }
     void run()
     {
@@ -193,6 +207,7 @@ struct RecordWriter {
             const int st = step;
             lk.unlock();
             must(fb_event_synchronize(e_copy), "record: wait for copies");
+            const auto w0 = std::chrono::steady_clock::now();
             char fn[1024];
             const char *names[5] = {"vort_src_input", "vort", "psi", "u", "v"};
             for (int i = 0; i < 5; ++i) {                                              // main.cpp:268-278, :187-220
@@ -210,6 +225,8 @@ struct RecordWriter {
                 if (lead) { fprintf(log_fd, "%s\n", fn); fflush(log_fd); }
             }
             if (feed) feed->release(src_buf);
+            busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            bytes += 5 * floats * sizeof(float);
             lk.lock();
             has_job = false;
             cv.notify_all();
@@ -333,12 +350,26 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
     eng->record(e_src);                                                                // d_in is free again behind this
     must(fb_event_synchronize(e_h2d), "sync");                                         // the pinned buffer goes back to the record path
 
+    // [timing] ("add steps/s + GB/s summary"; the reference prints no timing, main.cpp:262-264).  The step loop is
+    // never synchronised for it: time-stamped events on the compute stream bracket the stretches BETWEEN record steps -- a stretch ends
+    // where the record branch begins, before the host waits for the writer, and the next one begins behind the record kernels -- so
+    // their sum is the GPU time of the stepping alone; the host clock around the whole loop, writer included, gives the rate with records.
+    const bool timing = cfg.timing && cfg.total_steps > cfg.start_step;
+    std::vector<void *> t_beg, t_end;
+    auto stamp = [&](std::vector<void *> &v) { if (!timing) return; void *e = nullptr; must(fb_event_create_timing(&e), "event"); eng->record(e); v.push_back(e); };
+    eng->sync();
+    const auto wall0 = std::chrono::steady_clock::now();
+    int n_records = 0;
+    stamp(t_beg);
+
     // The reference can be restarted from any vort_step_N.bin via -i, but always renumbers from 0
     // (SURVEY section 5); --start-step N continues the numbering and the source clock instead.
     for (int step = cfg.start_step; step < cfg.total_steps; ++step) {                  // main.cpp:260
         const bool record = (step % cfg.record_step) == 0;
         if (lead) { printf("# Step %d, time = %.2f", step, step * cfg.dt); if (record) printf(", record now!"); printf("\n"); }
         if (record) {                                                                  // main.cpp:266-282 and the stage-0 dumps :181-222
+            stamp(t_end);
+            ++n_records;
             writer.wait_idle();                                                        // pinned buffers are free again
             if (copies_pending) eng->wait(e_copy);                                     // device record buffers are free again
             feed.hold(feed.cur);                                                       // vort_src as of this step (dumped BEFORE this step's read)
@@ -351,6 +382,7 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
             must(fb_event_record(e_copy, copy), "record");
             copies_pending = true;
             writer.submit(step);
+            stamp(t_beg);
         }
         if (cfg.recipe_type != EMPTY) {                                                // main-shallow-water.cpp:304
             const SourceFeed::Entry e = feed.read();
@@ -367,10 +399,29 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
         }
         eng->step();                                                                   // main.cpp:286-317
     }
+    stamp(t_end);
     writer.stop();
-    if (feed.shutdown()) delete feedp;
+    const bool feed_done = feed.shutdown();
     eng->sync();
     must(fb_stream_synchronize(copy), "sync");
+    if (timing) {
+        const double wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+        double gpu_ms = 0.0;
+        for (size_t k = 0; k < t_beg.size() && k < t_end.size(); ++k) { float ms = 0.0f; must(fb_event_elapsed_ms(t_beg[k], t_end[k], &ms), "elapsed"); gpu_ms += ms; }
+        for (void *e : t_beg) fb_event_destroy(e);
+        for (void *e : t_end) fb_event_destroy(e);
+        if (lead) {
+            const int steps = cfg.total_steps - cfg.start_step;
+            const double rate = steps / (gpu_ms * 1e-3), gbs = 320.0 * N * (double)N * rate / 1e9, peak = 8000.0 * P;    // B_alg = 320 N^2 per step; HBM3E 8 TB/s per GPU
+            fprintf(stderr, "[timing] %d RK4 steps, %d x %d grid, %d GPU%s: step loop without the record steps %.1f steps/s (%.4f ms/step) = %.0f GB/s by 320 N^2 B/step = %.3f of %.0f GB/s\n",
+                    steps, N, N, P, P > 1 ? "s" : "", rate, gpu_ms / steps, gbs, gbs / peak, peak);
+            fprintf(stderr, "[timing] with %d record steps (%.3f GB written%s): %.1f steps/s over %.3f s of wall time; the writer thread was busy %.3f s = %.2f GB/s to %s\n",
+                    n_records, writer.bytes * (double)(P > 1 && !cfg.threads ? P : 1) / 1e9, P > 1 && !cfg.threads ? ", all ranks" : (P > 1 ? ", this rank" : ""), steps / wall_s, wall_s, writer.busy_s,
+                    writer.busy_s > 0 ? writer.bytes / writer.busy_s / 1e9 : 0.0, cfg.output.c_str());
+            fflush(stderr);
+        }
+    }
+    if (feed_done) delete feedp;
     fb_free(d_in); for (auto p : d_out) fb_free(p);
     for (int i = 0; i < 4; ++i) fb_free_host(writer.h[i]);
     delete eng;
@@ -386,6 +437,7 @@ int main(int argc, char *args[])
                                     {"steps", 1, 0, 6}, {"record-step", 1, 0, 7}, {"start-step", 1, 0, 8},
                                     {"world", 1, 0, 9}, {"rank", 1, 0, 10}, {"comm-file", 1, 0, 11}, {"ranks-as-threads", 0, 0, 12},
                                     {"launch-token", 1, 0, 13}, {"comm-max-age", 1, 0, 14}, {"comm-timeout", 1, 0, 15}, {"fifo-fanout", 0, 0, 16},
+                                    {"no-timing", 0, 0, 17},
                                     {0, 0, 0, 0}};
     int opt;
     while ((opt = getopt_long(argc, args, "I:O:i:s:f:", lopts, NULL)) != EOF) {      // main.cpp:68-80, main-shallow-water.cpp:75-95
@@ -411,6 +463,7 @@ int main(int argc, char *args[])
         case 14: cfg.comm_max_age = atol(optarg); break;
         case 15: cfg.comm_timeout = atol(optarg); break;
         case 16: cfg.fanout = true; break;
+        case 17: cfg.timing = false; break;
         }
     }
     if (cfg.world < 1 || cfg.rank < 0 || cfg.rank >= cfg.world || (cfg.world > 1 && !cfg.threads && cfg.comm_file.empty()) ||

@@ -95,6 +95,41 @@ def stage_schedule(nx, ny, world):
     return ops
 
 
+LINK_GBS = 60.0         # assumed xGMI rate per direction and peer (7 links x ~153 GB/s bidirectional per GPU: <= 77 GB/s one way)
+GROUP_LATENCY_MS = 0.03  # assumed cost of one grouped ncclSend/ncclRecv beyond its bytes
+
+
+def predicted_step_ms(nx, ny, world, local_ms_per_step=None):
+    """DESIGN.md section 6's model of one multi-GPU RK4 step, as numbers (a PREDICTION: no node has been available to the builder).
+    Per stage a rank sends 5 fields x XL x KA complex to every peer, all peers at once on their own links:
+        t_link   = 5 XL KA 8 B / LINK_GBS  +  2 dependent collectives x GROUP_LATENCY_MS
+        local    = the rank's passes of a stage: local_ms_per_step / 4 where measured (bench.py's null-transport run), else
+                   22.4 C / world at 5 TB/s
+        exposed  = the part of `local` no transfer hides: with two column groups the first row chunk (5.0/22.5 of local / chunks; the
+                   shares are the kernels' counter bytes per stage, DESIGN.md section 4: 8.3 + 1.9 + 7.3 + 5.0 C); otherwise the forward
+                   x pass + update (10.2/22.5), the first field group's backward sub-pass (7.3/22.5 / groups) and the first row chunk
+        stage    = t_link + exposed;  step = 4 stages.
+    Returns (ms per step, dict of the terms)."""
+    xl, ka, _ = slab_geometry(nx, ny, world)
+    fg, ch = stage_plan(nx, ny, world)
+    ncg = len(slab_col_groups(nx, ny, world))
+    hy = ny // 2 + 1
+    if local_ms_per_step is None:
+        local = 22.4 * 8.0 * nx * _round16(hy) / world / 5e12 * 1e3
+    else:
+        local = local_ms_per_step / 4.0
+    if world == 1:
+        return 4.0 * local, {"t_link_ms": 0.0, "local_ms": local, "exposed_ms": local}
+    t_link = 5.0 * xl * ka * 8.0 / (LINK_GBS * 1e9) * 1e3 + 2 * GROUP_LATENCY_MS
+    if ncg > 1:
+        exposed = local * (5.0 / 22.5) / ch
+    else:
+        exposed = local * (10.2 / 22.5 + 7.3 / 22.5 / fg + 5.0 / 22.5 / ch)
+    return 4.0 * (t_link + exposed), {"t_link_ms_per_stage": t_link, "local_ms_per_stage": local, "exposed_ms_per_stage": exposed,
+                                      "link_GBs_assumed": LINK_GBS, "group_latency_ms_assumed": GROUP_LATENCY_MS,
+                                      "local_from": "measured (null transport)" if local_ms_per_step is not None else "22.4 C / world at 5 TB/s"}
+
+
 def local_rows(field, rank, world):
     xl = field.shape[0] // world
     return np.ascontiguousarray(field[rank * xl:(rank + 1) * xl])
@@ -268,6 +303,16 @@ class EngineSlab:
         bad = C.c_size_t()
         self.B.check(self.L.fb_slab_transport_selftest(self._h, count, C.byref(bad)))
         return int(bad.value)
+
+    def transport_info(self):
+        """What is connected, as the transport's own communicator reports it (fb_slab_transport_info): for RCCL the values of
+        ncclCommCount / ncclCommUserRank / ncclCommCuDevice -- the proof that `world` ranks joined ONE communicator -- and this
+        rank's HIP device ordinal.  -1 where the transport has no communicator (gloo callback, in-process hub)."""
+        name = C.create_string_buffer(32)
+        v = [C.c_int() for _ in range(4)]
+        self.B.check(self.L.fb_slab_transport_info(self._h, name, 32, *[C.byref(x) for x in v]))
+        return {"name": name.value.decode(), "comm_ranks": v[0].value, "comm_rank": v[1].value, "comm_device": v[2].value,
+                "hip_device": v[3].value}
 
     def time_steps(self, n):
         ms = C.c_float()
