@@ -313,6 +313,13 @@ def test_1000_steps_tolerance_1024(X, O, R):
     print("n=1024: rel L2 (every 4th point) after 1000 steps = %.3e" % err)
     assert err < 1e-5
     assert abs(np.linalg.norm(got.astype(np.float64)) / float(G["l2"]) - 1) < 1e-5
+    # ... and DIRECTLY against the independent fp64 run (tests/ref_numpy.py Model64 on numpy's rfft2 / irfft2: neither the oracle's
+    # code nor its FFT; tests/golden/fp64_1024_step1000.npz), not only through the oracle
+    G64 = np.load(os.path.join(HERE, "golden", "fp64_1024_step1000.npz"))
+    err64 = R.rel_l2(got[::4, ::4].astype(np.float64), G64["vort_sub4"])
+    print("n=1024: rel L2 against the independent fp64 run after 1000 steps = %.3e" % err64)
+    assert err64 < 1e-5
+    assert abs(np.linalg.norm(got.astype(np.float64)) / float(G64["l2"]) - 1) < 1e-5
 
 
 def test_single_pass_x_transform_matches_three_kernel_path(O, R):
@@ -592,6 +599,23 @@ def test_frozen_mode_shortcuts_are_bitwise_neutral_4096(O, R):
     assert R.rel_l2(np.ascontiguousarray(full["spec"][:, -20:]).view(np.float32), np.ascontiguousarray(hi).view(np.float32)) < 2e-6     # one 2-D transform of white noise
     psi, u, v = mo.diag()
     assert R.rel_l2(full["u"], u[::8, ::8]) < 1e-5 and R.rel_l2(full["psi"], psi[::8, ::8]) < 1e-5
+
+
+def test_three_kernel_path_is_bitwise_independent_of_the_pitch_4096():
+    """The row pitch of the engine's private arrays is a performance knob, and on the three-kernel x pass --
+    16384^2 on one GPU, every multi-GPU rank -- it is chosen by a TIMING probe when the context is created (autotune_pitch), so two runs
+    may use different pitches.  Results must not depend on it: FB_FULL_PASS=0 with the probe's choice against the fixed pitches
+    minimum + 0 / 16 / 48 columns (FB_PITCH_EXTRA = 0 / 1 / 3) and against the probe switched off, bit for bit in vort(), spectrum()
+    and diag() on the never-dealiased noise state (pad columns are zero and stay zero because every pass is linear)."""
+    import tempfile
+    steps = 2
+    with tempfile.TemporaryDirectory() as d:
+        probed = _noise_run({"FB_FULL_PASS": "0"}, steps, d, "three")
+        runs = {"extra%s" % k: _noise_run({"FB_FULL_PASS": "0", "FB_PITCH_EXTRA": k}, steps, d, "three_p" + k) for k in ("0", "1", "3")}
+        runs["no_probe"] = _noise_run({"FB_FULL_PASS": "0", "FB_NO_PITCH_TUNE": "1"}, steps, d, "three_np")
+    for tag, r in runs.items():
+        for k in ("vort", "spec", "u", "psi"):
+            assert np.array_equal(probed[k].view(np.uint32), r[k].view(np.uint32)), (tag, k)
 
 
 def test_single_pass_and_three_kernel_paths_agree_over_600_steps_4096(R):

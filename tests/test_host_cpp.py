@@ -92,6 +92,53 @@ def test_driver_outputs_match_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_driver_optional_debug_dumps(tmp_path):
+    """--dump-grad-vort / --dump-dvortdt: the OUTPUT_GRAD_VORT and OUTPUT_DVORTDT blocks of getDvortdt(debug) (main.cpp:156-162,
+    170-176,229-235; not defined in the reference's configuration.hpp:4-5, which switches on OUTPUT_PSI and OUTPUT_WIND only).  With both
+    on, a record step logs vort_src_input, vort, dvortdx, dvortdy, psi, u, v, dvortdt in that order; the values against the oracle's
+    intermediates at 256^2 (steps 0 and 100); without the options the log is the five-file one."""
+    import oracle_py as O
+    import ref_numpy as R
+    _build()
+    n = 256
+    (tmp_path / "input").mkdir()
+    (tmp_path / "output").mkdir()
+    v0 = O.make_field("elliptic", n)
+    v0.tofile(str(tmp_path / "input" / "initial_vorticity.bin"))
+    subprocess.run([os.path.join(HOST, "barotropic_main.out"), "--npts", str(n), "--steps", "101", "--dump-grad-vort", "--dump-dvortdt"],
+                   cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    log = (tmp_path / "log").read_text().split()
+    order = ("vort_src_input", "vort", "dvortdx", "dvortdy", "psi", "u", "v", "dvortdt")
+    assert log == ["output/%s_step_%d.bin" % (name, s) for s in (0, 100) for name in order]
+    rd = lambda name: np.fromfile(str(tmp_path / "output" / name), dtype="<f4").reshape(n, n)
+    ops = O.Operators(n, n, 6e5, 6e5)
+    g = np.float32(n * n)
+    m = O.Model(n, n)
+    m.set_vort(v0)
+    for s_ in (0, 100):
+        vc = m.spectrum()
+        dzdx = O.c2r(ops.gradx(vc), n) / g                                        # main.cpp:151-154
+        dzdy = O.c2r(ops.grady(vc), n) / g                                        # main.cpp:165-168
+        psi, u, v = m.diag()
+        t = -u * dzdx - v * dzdy + np.float32(0)                                  # main.cpp:225-227
+        assert R.rel_l2(rd("dvortdx_step_%d.bin" % s_), dzdx) < 1e-5 and R.rel_l2(rd("dvortdy_step_%d.bin" % s_), dzdy) < 1e-5
+        assert R.rel_l2(rd("dvortdt_step_%d.bin" % s_), t) < 1e-5
+        assert R.rel_l2(rd("u_step_%d.bin" % s_), u) < 1e-5 and R.rel_l2(rd("vort_step_%d.bin" % s_), m.vort()) < 1e-5
+        # the dump is the Jacobian of the dumped fields, bit for bit (the standalone kernel keeps the reference's evaluation order)
+        tj = -rd("u_step_%d.bin" % s_) * rd("dvortdx_step_%d.bin" % s_) - rd("v_step_%d.bin" % s_) * rd("dvortdy_step_%d.bin" % s_) + np.float32(0)
+        assert np.array_equal(rd("dvortdt_step_%d.bin" % s_), tj)
+        m.step(100)
+    plain = tmp_path / "plain"
+    (plain / "output").mkdir(parents=True)
+    subprocess.run([os.path.join(HOST, "barotropic_main.out"), "--npts", str(n), "--steps", "1", "-I", "../input"], cwd=str(plain),
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    assert (plain / "log").read_text().split() == ["output/%s_step_0.bin" % name for name in ("vort_src_input", "vort", "psi", "u", "v")]
+    multi = subprocess.run([os.path.join(HOST, "barotropic_main.out"), "--npts", str(n), "--steps", "1", "--world", "2", "--ranks-as-threads",
+                            "--dump-dvortdt"], cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    assert multi.returncode == 2 and "one GPU only" in multi.stderr
+
+
+@pytest.mark.gpu
 def test_driver_4096_default_path(tmp_path):
     """The drop-in driver on the benchmark grid (4096^2 Kuo2004, dt = 0.75 s): there the engine takes its
     single-pass x transform and the digit-permutation row kernel, and the record path (get_vort / get_diag)

@@ -10,10 +10,10 @@ tag=${1:-r02_x}; n=${2:-4096}; k=${3:-20}; cpu=${4:-5}
 out=gpurun_out/prof_${tag}_$n
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf $out && mkdir -p $out
-B="python3 bench.py --grid $n --steps $k --warmup 3 --cpu-steps 0"
+B="python3 bench.py --grid $n --steps $k --warmup 3 --cpu-steps 0 --driver-steps 0"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/stats -o p --output-format csv -- $B > $out/stats.log 2>&1 &&
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o p --output-format csv -- python3 bench.py --grid $n --steps 3 --warmup 1 --cpu-steps 0 > $out/fetch.log 2>&1 &&
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o p --output-format csv -- python3 bench.py --grid $n --steps 3 --warmup 1 --cpu-steps 0 > $out/write.log 2>&1 &&
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o p --output-format csv -- python3 bench.py --grid $n --steps 3 --warmup 1 --cpu-steps 0 --driver-steps 0 > $out/fetch.log 2>&1 &&
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o p --output-format csv -- python3 bench.py --grid $n --steps 3 --warmup 1 --cpu-steps 0 --driver-steps 0 > $out/write.log 2>&1 &&
 timeout -k 10 900 python3 bench.py --grid $n --cpu-steps $cpu > $out/bench.json 2> $out/bench.err
 python3 tools/pmc_summary.py $out/fetch $out/write > $out/pmc.json
 find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv

@@ -660,3 +660,162 @@ __global__ void __launch_bounds__(1024) k_rowh2(RowArgs a, const cf *__restrict_
         }
     }
 }
+
+
+#ifdef RH2_SPLIT_EXPERIMENT
+// =====================================================================================================================
+// k_rowh2s -- TIMING EXPERIMENT of round 4 (never compiled into the product: results are wrong, the forward
+// radix-2 step over x is left out).  k_rowh2 as TWO independent 512-thread workgroups per x2, two resident per CU as k_rowh<1>:
+// workgroup (x2, h) produces the physical row x = x2 + 4096 h alone.  It needs both half-transformed rows Y_0[x2], Y_1[x2] of every
+// field, and a CU's LDS holds one exchange buffer (37 KB) + ONE staged row (32 KB) per context when two contexts share it (two staged
+// rows: 101 KB, one context per CU).  So Y_0 arrives by LDS-DMA one phase ahead as before and Y_1 is read into registers at the
+// point of use (8 B per lane, 512 B per wave instruction); the partner workgroup (h' = 1 - h) is the block 8 ids further on, i.e. the
+// next one on the same XCD, so that the second reader of a row can find it in that XCD's L2.  The tendency row T_h is stored as it
+// is: in the real variant k_col_full<., 2> would form U_k1 = W^{k1 x2}(T_0 + (-1)^{k1} T_1) on load (a second read of the tendency).
+// =====================================================================================================================
+#ifndef RH2S_HALVES
+#define RH2S_HALVES 1      /* 1: Y_1 in two batches of four e (16 registers in flight, the second batch travels while the first is used); 0: all sixteen loads at once */
+#endif
+FB_DEV void rh2s_one(cf *v, int e, int t, const cf *stg0, cf y1k, cf y1m, cf wh, cf wx)
+{
+    constexpr int M = RowH2::M;
+    const int k = t + 512 * e;
+    cf a = cadd(lds_rd(&stg0[k]), cmul(y1k, wh));                                     // X_h[k]
+    cf b = cadd(lds_rd(&stg0[M - k]), cmul(y1m, wh));                                 // X_h[M-k]
+    if (e == 0 && t == 0) { a.y = 0.f; b.y = 0.f; }
+    const cf ev = cadd_conj(a, b);
+    cf d = cmul(csub_conj(a, b), wx);
+    switch (e) {
+    case 1: d = mul_w16<1, +1>(d); break; case 2: d = mul_w16<2, +1>(d); break; case 3: d = mul_w16<3, +1>(d); break;
+    case 4: d = mul_w16<4, +1>(d); break; case 5: d = mul_w16<5, +1>(d); break; case 6: d = mul_w16<6, +1>(d); break;
+    case 7: d = mul_w16<7, +1>(d); break; default: break;
+    }
+    v[e] = cadd_ib(ev, d);
+}
+FB_DEV void rh2s_ext(cf *v, int t, const cf *stg0, const cf *__restrict__ g1, cf wh, cf wx)
+{
+    constexpr int M = RowH2::M;
+#if RH2S_HALVES
+    cf ya[4], yb[4], yc[4], yd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int k = t + 512 * e; ya[e] = g1[k]; yb[e] = g1[M - k]; }
+    RH_WAIT_ROW();                                                    // Y_0 (sent for a phase ago) and the eight loads above
+    lds_barrier();
+#pragma unroll
+    for (int e = 4; e < 8; ++e) { const int k = t + 512 * e; yc[e - 4] = g1[k]; yd[e - 4] = g1[M - k]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rh2s_one(v, e, t, stg0, ya[e], yb[e], wh, wx);
+    RH_WAIT_ROW();
+#pragma unroll
+    for (int e = 4; e < 8; ++e) rh2s_one(v, e, t, stg0, yc[e - 4], yd[e - 4], wh, wx);
+#else
+    cf y1k[8], y1m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int k = t + 512 * e; y1k[e] = g1[k]; y1m[e] = g1[M - k]; }
+    RH_WAIT_ROW();                                                    // Y_0 (sent for a phase ago) and the sixteen loads above
+    lds_barrier();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rh2s_one(v, e, t, stg0, y1k[e], y1m[e], wh, wx);
+#endif
+}
+
+__global__ void __launch_bounds__(512, 4) k_rowh2s(RowArgs a, const cf *__restrict__ root4096, const cf *__restrict__ rootN, int pairs_per_iter)
+{
+    using C = RowH<1>;
+    constexpr int M = C::M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *xbuf = reinterpret_cast<cf *>(smem_raw);
+    cf *stg = xbuf + C::XBUF;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    Row8Tw tw;
+#pragma unroll
+    for (int p = 1; p < 8; ++p) tw.w0[p - 1] = root4096[p * t];
+    cf *tw2 = stg + C::STG;
+    if (t < 64) tw2[t] = root4096[64 * (t & 7) * (t >> 3)];
+    tw.w2 = tw2;
+    cf *tw1 = tw2 + C::TW2;                                          // W_512^{p l} at [p - 1][l]: read per phase instead of living in 14 registers
+    if (t < 448) tw1[t] = root4096[8 * (1 + (t >> 6)) * (t & 63)];
+    const cf wq = cf_make(1.f, 0.f);
+    cf wx;
+    { const cf r = rootN[t]; wx = cf_make(r.x, -r.y); }
+#pragma unroll
+    for (int p = 0; p < 7; ++p) asm volatile("" :: "v"(tw.w0[p]));
+    asm volatile("" :: "v"(wx));
+    __syncthreads();
+
+    // blocks b and b + 8 (the same XCD, consecutive there) are the two halves of one x2
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3, h = j & 1, q = (j >> 1) * 8 + xcd;
+    const long sub = a.sub_rows;
+    const int iters = (a.nx + pairs_per_iter - 1) / pairs_per_iter;
+    auto row_of = [&](int it, bool &valid) { const int r = it * pairs_per_iter + q; valid = r < a.nx; return a.x0 + (valid ? r : 0); };
+    if (iters > 0) { bool vld; const int x2 = row_of(0, vld); rh_dma_issue<1, false>(stg, t, a.M, 0, x2); }
+    for (int it = 0; it < iters; ++it) {
+        bool valid;
+        const int x2 = row_of(it, valid);
+        bool vn = false;
+        const int xn = (it + 1 < iters) ? row_of(it + 1, vn) : -1;
+        const cf wb = a.tw_x[x2];
+        const cf wh = h ? cf_make(-wb.x, wb.y) : cf_make(wb.x, -wb.y);
+        const int xrow = (int)(h * sub) + x2;
+        cf v1[1][8];
+        cf (&v)[8] = v1[0];
+        cf p[8];
+        auto c2r_phase = [&](int field, int next_field, int next_x2) {
+            const int tp = launder(t);
+            rh2s_ext(v, tp, stg, row_ptr<false>(a.M, field, (int)sub + x2, 0), wh, wx);
+            lds_barrier();
+            if (next_x2 >= 0) rh_dma_issue<1, false>(stg, tp, a.M, next_field, next_x2);
+#pragma unroll
+            for (int p = 0; p < 7; ++p) tw.w1[p] = lds_rd(&tw1[p * 64 + (tp & 63)]);
+            rh_bwd<1>(v1, xbuf, tw, wq, tp >> 6, tp & 63, RhNothing());
+        };
+        c2r_phase(0, 2, x2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] = cf_make(v[e].x * a.scale, v[e].y * a.scale);
+        c2r_phase(2, 1, x2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] = cf_make((v[e].x * a.scale) * p[e].x, (v[e].y * a.scale) * p[e].y);
+        c2r_phase(1, 3, x2);
+        {
+            cf zy[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zy[e] = cf_make(v[e].x * a.scale, v[e].y * a.scale);
+            c2r_phase(3, 0, xn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = cf_make(p[e].x - (v[e].x * a.scale) * zy[e].x, p[e].y - (v[e].y * a.scale) * zy[e].y);
+        }
+        const int tt = launder(t), wl = tt >> 6, ll = tt & 63;
+#pragma unroll
+        for (int p = 0; p < 7; ++p) tw.w1[p] = lds_rd(&tw1[p * 64 + ll]);
+        rh_fwd<1>(v1, xbuf, tw, wq, wl, ll);
+        lds_barrier();
+#pragma unroll
+        for (int e = 4; e < 8; ++e) lds_wr(&xbuf[tt + 512 * (e - 4)], v[e]);
+        lds_barrier();
+        if (valid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = tt + 512 * e;
+                const cf wk = v[e];
+                if (k == 0) {
+                    *const_cast<cf *>(row_ptr<false>(a.T, 0, xrow, 0)) = cf_make(wk.x + wk.y, 0.f);
+                    *const_cast<cf *>(row_ptr<false>(a.T, 0, xrow, M)) = cf_make(wk.x - wk.y, 0.f);
+                    continue;
+                }
+                const cf wm = lds_rd(&xbuf[M / 2 - k]);
+                const cf ev = cf_make(0.5f * (wk.x + wm.x), 0.5f * (wk.y - wm.y));
+                const cf od = cf_make(0.5f * (wk.y + wm.y), 0.5f * (wm.x - wk.x));
+                cf co = cmulc(od, wx);
+                switch (e) {
+                case 1: co = mul_w16<1, -1>(co); break; case 2: co = mul_w16<2, -1>(co); break; case 3: co = mul_w16<3, -1>(co); break;
+                default: break;
+                }
+                st2<false>(const_cast<cf *>(row_ptr<false>(a.T, 0, xrow, k)), cadd(ev, co));
+                const cf tm = csub(ev, co);
+                st2<false>(const_cast<cf *>(row_ptr<false>(a.T, 0, xrow, M - k)), cf_make(tm.x, -tm.y));
+            }
+            if (tt == 0) { const cf wh2 = v[4]; *const_cast<cf *>(row_ptr<false>(a.T, 0, xrow, M / 2)) = cf_make(wh2.x, -wh2.y); }
+        }
+    }
+}
+#endif  // RH2_SPLIT_EXPERIMENT

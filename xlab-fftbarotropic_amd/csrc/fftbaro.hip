@@ -633,6 +633,20 @@ static int launch_rowq(fb_ctx *c, const RowArgs &a)
 
 static int launch_rowh2(fb_ctx *c, const RowArgs &a)
 {
+#ifdef RH2_SPLIT_EXPERIMENT   /* timing experiment (fb_rowh.h, k_rowh2s): two 512-thread workgroups per x2; results are wrong */
+    if (getenv("FB_ROWH2_SPLIT")) {
+        int grid = 2 * a.nx, cap = c->max_wg / 4;              // two resident workgroups per CU; FB_ROW_GRID=16384: one workgroup per (x2, h)
+        if (const char *e = getenv("FB_ROW_GRID")) { int v = atoi(e); if (v >= 64) cap = v; }
+        if (grid > cap) grid = cap;
+        grid &= ~15;
+        const size_t lds = RowH<1>::LDS_BYTES + 448 * sizeof(cf);
+        int rc = set_max_lds(c, (const void *)k_rowh2s, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_rowh2s, dim3(grid), dim3(512), lds, c->stream, a, (const cf *)c->d_tw_4096, (const cf *)c->d_tw_row3, grid / 2);
+        HIPCHK(hipGetLastError());
+        return FB_OK;
+    }
+#endif
     int grid = a.nx, cap = c->max_wg / 8;         // one 1024-thread workgroup per CU, each loops over x2
     if (const char *e = getenv("FB_ROW_GRID")) { int v = atoi(e); if (v >= 64) cap = v; }
     if (grid > cap) grid = cap;

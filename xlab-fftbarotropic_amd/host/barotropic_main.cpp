@@ -56,6 +56,7 @@ struct Config {
     int world = 1, rank = 0; bool threads = false, fanout = false;
     long comm_max_age = 60, comm_timeout = 600;
     bool timing = true;                                                            // the [timing] summary on stderr (--no-timing: off)
+    bool dump_grad = false, dump_dvortdt = false;                                  // the OUTPUT_GRAD_VORT / OUTPUT_DVORTDT blocks of main.cpp:156-162,170-176,229-235 as run-time options
 };
 
 // --fifo-fanout (multi-GPU, SURVEY.md section 8(e) "rank 0 reads, scatters x-slabs"): ONE producer that writes whole fields -- the
@@ -192,7 +193,9 @@ struct SourceFeed {
 struct RecordWriter {
     std::thread th; std::mutex mu; std::condition_variable cv;
     bool has_job = false, quit = false; int step = 0;
-    void *e_copy = nullptr; float *h[4] = {nullptr, nullptr, nullptr, nullptr};
+    void *e_copy = nullptr; float *h[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // what a record step writes, in the reference's order (main.cpp:266-282, then the stage-0 dumps :156-235): name and buffer (-1 = vort_src)
+    std::vector<std::pair<const char *, int> > items;
     const float *src = nullptr; int src_buf = -1; SourceFeed *feed = nullptr;          // vort_src as of the record step
     std::string output; FILE *log_fd = nullptr; size_t floats = 0;
     bool whole = true, lead = true; off_t off = 0;                                     // whole file (writeField) or this rank's byte range
@@ -209,10 +212,9 @@ struct RecordWriter {
             must(fb_event_synchronize(e_copy), "record: wait for copies");
             const auto w0 = std::chrono::steady_clock::now();
             char fn[1024];
-            const char *names[5] = {"vort_src_input", "vort", "psi", "u", "v"};
-            for (int i = 0; i < 5; ++i) {                                              // main.cpp:268-278, :187-220
-                snprintf(fn, sizeof fn, "%s/%s_step_%d.bin", output.c_str(), names[i], st);
-                const float *data = i == 0 ? src : h[i - 1];
+            for (size_t i = 0; i < items.size(); ++i) {                                // main.cpp:268-278, :156-235
+                snprintf(fn, sizeof fn, "%s/%s_step_%d.bin", output.c_str(), items[i].first, st);
+                const float *data = items[i].second < 0 ? src : h[items[i].second];
                 if (whole) must(fb_write_field(fn, data, floats), "writeField");
                 else {
                     const int fd = open(fn, O_WRONLY | O_CREAT, 0644);
@@ -226,7 +228,7 @@ struct RecordWriter {
             }
             if (feed) feed->release(src_buf);
             busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-            bytes += 5 * floats * sizeof(float);
+            bytes += items.size() * floats * sizeof(float);
             lk.lock();
             has_job = false;
             cv.notify_all();
@@ -247,6 +249,9 @@ struct Engine {
     virtual void set_source(const float *d) = 0;                                      // main-shallow-water.cpp:304
     virtual void step() = 0;                                                          // main.cpp:286-317
     virtual void sync() = 0;
+    // the optional stage-0 dumps of getDvortdt(debug) (main.cpp:156-162,170-176,229-235): dvortdx, dvortdy and
+    // dvortdt = -u dvortdx - v dvortdy + vort_src of the CURRENT state (u, v as get() returned them; src NULL = zeros); any output may be NULL
+    virtual void get_debug(float *d_dzdx, float *d_dzdy, float *d_dzdt, const float *d_u, const float *d_v, const float *d_src) = 0;
 };
 struct SingleEngine : Engine {
     fb_ctx *fop = nullptr; fb_model *model = nullptr; void *compute = nullptr;
@@ -256,8 +261,9 @@ struct SingleEngine : Engine {
         must(fb_stream_create(&compute), "stream");
         must(fb_set_stream(fop, compute), "fb_set_stream");
         must(fb_model_create(&model, fop, cfg.NU, cfg.dt), "fb_model_create");
+        npts = cfg.npts;
     }
-    ~SingleEngine() { fb_model_destroy(model); fb_destroy(fop); fb_stream_destroy(compute); }
+    ~SingleEngine() { for (float *p : {d_spec, d_tmp, d_gx, d_gy}) if (p) fb_free(p); fb_model_destroy(model); fb_destroy(fop); fb_stream_destroy(compute); }
     void set_vort(const float *d) override { must(fb_model_set_vort(model, d), "fb_model_set_vort"); }
     void get(float *a, float *b, float *c, float *d) override
     {
@@ -269,6 +275,24 @@ struct SingleEngine : Engine {
     void set_source(const float *d) override { must(fb_model_set_source(model, d), "fb_model_set_source"); }
     void step() override { must(fb_model_step(model, 1), "fb_model_step"); }
     void sync() override { must(fb_synchronize(fop), "sync"); }
+    float *d_spec = nullptr, *d_tmp = nullptr, *d_gx = nullptr, *d_gy = nullptr; size_t nreal = 0;
+    void get_debug(float *d_dzdx, float *d_dzdy, float *d_dzdt, const float *d_u, const float *d_v, const float *d_src) override
+    {
+        // the reference's own operator sequence on vort_c (main.cpp:151-168,225-227) through the operator entry points of the C ABI
+        // (bit-exact standalone kernels): off the hot path, only on record steps and only when asked for
+        if (!d_spec) {
+            nreal = (size_t)npts * npts;
+            const size_t spec = (size_t)npts * (npts / 2 + 1) * 2 * sizeof(float);
+            must(fb_malloc((void **)&d_spec, spec), "fb_malloc"); must(fb_malloc((void **)&d_tmp, spec), "fb_malloc");
+            must(fb_malloc((void **)&d_gx, nreal * sizeof(float)), "fb_malloc"); must(fb_malloc((void **)&d_gy, nreal * sizeof(float)), "fb_malloc");
+        }
+        must(fb_model_get_spectrum(model, d_spec), "fb_model_get_spectrum");
+        float *gx = d_dzdx ? d_dzdx : d_gx, *gy = d_dzdy ? d_dzdy : d_gy;
+        must(fb_gradx(fop, d_spec, d_tmp), "gradx"); must(fb_c2r(fop, d_tmp, gx, 1), "c2r");          // main.cpp:151,154
+        must(fb_grady(fop, d_spec, d_tmp), "grady"); must(fb_c2r(fop, d_tmp, gy, 1), "c2r");          // main.cpp:165,168
+        if (d_dzdt) must(fb_jacobian(fop, d_u, d_v, gx, gy, d_src, d_dzdt), "jacobian");               // main.cpp:225-227
+    }
+    int npts = 0;
 };
 struct SlabEngine : Engine {
     fb_slab *sl = nullptr;
@@ -299,6 +323,10 @@ struct SlabEngine : Engine {
     void set_source(const float *d) override { must(fb_slab_set_source_local(sl, d), "fb_slab_set_source_local"); }
     void step() override { must(fb_slab_step(sl, 1), "fb_slab_step"); }
     void sync() override { must(fb_slab_synchronize(sl), "sync"); }
+    void get_debug(float *, float *, float *, const float *, const float *, const float *) override
+    {
+        std::fprintf(stderr, "--dump-grad-vort / --dump-dvortdt: one GPU only\n"); std::exit(2);      // (refused in main() already)
+    }
 };
 
 // ---- one rank's run: the whole program when world == 1 --------------------------------------------------------------------------
@@ -311,12 +339,18 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
     void *copy = nullptr, *e_rec = nullptr, *e_copy = nullptr, *e_h2d = nullptr, *e_src = nullptr;
     must(fb_stream_create(&copy), "stream");
     for (void **e : {&e_rec, &e_copy, &e_h2d, &e_src}) must(fb_event_create(e), "event");
-    float *d_in = nullptr, *d_out[4] = {nullptr, nullptr, nullptr, nullptr};
+    // record buffers 0..3 = vort, psi, u, v; 4, 5 = dvortdx, dvortdy (--dump-grad-vort); 6 = dvortdt (--dump-dvortdt)
+    const bool use[7] = {true, true, true, true, cfg.dump_grad, cfg.dump_grad, cfg.dump_dvortdt};
+    float *d_in = nullptr, *d_out[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     must(fb_malloc((void **)&d_in, floats * sizeof(float)), "fb_malloc");
-    for (auto &p : d_out) must(fb_malloc((void **)&p, floats * sizeof(float)), "fb_malloc");
+    for (int i = 0; i < 7; ++i) if (use[i]) must(fb_malloc((void **)&d_out[i], floats * sizeof(float)), "fb_malloc");
 
     RecordWriter writer;
-    for (int i = 0; i < 4; ++i) must(fb_malloc_host((void **)&writer.h[i], floats * sizeof(float)), "fb_malloc_host");
+    for (int i = 0; i < 7; ++i) if (use[i]) must(fb_malloc_host((void **)&writer.h[i], floats * sizeof(float)), "fb_malloc_host");
+    writer.items = {{"vort_src_input", -1}, {"vort", 0}};                              // main.cpp:268-278
+    if (cfg.dump_grad) { writer.items.push_back({"dvortdx", 4}); writer.items.push_back({"dvortdy", 5}); }   // main.cpp:156-162,170-176
+    writer.items.push_back({"psi", 1}); writer.items.push_back({"u", 2}); writer.items.push_back({"v", 3});   // main.cpp:181-222
+    if (cfg.dump_dvortdt) writer.items.push_back({"dvortdt", 6});                      // main.cpp:229-235
     writer.e_copy = e_copy; writer.output = cfg.output; writer.log_fd = log_fd; writer.floats = floats;
     writer.whole = P == 1; writer.lead = lead; writer.off = off;
     writer.start();
@@ -376,9 +410,14 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
             writer.src = feed.cur >= 0 ? feed.pin[feed.cur] : zeros.data();
             writer.src_buf = feed.cur;
             eng->get(d_out[0], d_out[1], d_out[2], d_out[3]);
+            if (cfg.dump_grad || cfg.dump_dvortdt) {
+                // vort_src on the device: d_in holds the source in force once one has been uploaded (before that: zeros = NULL)
+                eng->get_debug(d_out[4], d_out[5], d_out[6], d_out[2], d_out[3], feed.cur >= 0 ? d_in : nullptr);
+                eng->record(e_src);                                                    // d_in may be overwritten behind this
+            }
             eng->record(e_rec);
             must(fb_stream_wait_event(copy, e_rec), "wait");
-            for (int i = 0; i < 4; ++i) must(fb_memcpy_d2h_async(copy, writer.h[i], d_out[i], floats * sizeof(float)), "d2h");
+            for (int i = 0; i < 7; ++i) if (use[i]) must(fb_memcpy_d2h_async(copy, writer.h[i], d_out[i], floats * sizeof(float)), "d2h");
             must(fb_event_record(e_copy, copy), "record");
             copies_pending = true;
             writer.submit(step);
@@ -422,8 +461,8 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
         }
     }
     if (feed_done) delete feedp;
-    fb_free(d_in); for (auto p : d_out) fb_free(p);
-    for (int i = 0; i < 4; ++i) fb_free_host(writer.h[i]);
+    fb_free(d_in); for (auto p : d_out) if (p) fb_free(p);
+    for (int i = 0; i < 7; ++i) if (writer.h[i]) fb_free_host(writer.h[i]);
     delete eng;
     for (void *e : {e_rec, e_copy, e_h2d, e_src}) fb_event_destroy(e);
     fb_stream_destroy(copy);
@@ -437,7 +476,7 @@ int main(int argc, char *args[])
                                     {"steps", 1, 0, 6}, {"record-step", 1, 0, 7}, {"start-step", 1, 0, 8},
                                     {"world", 1, 0, 9}, {"rank", 1, 0, 10}, {"comm-file", 1, 0, 11}, {"ranks-as-threads", 0, 0, 12},
                                     {"launch-token", 1, 0, 13}, {"comm-max-age", 1, 0, 14}, {"comm-timeout", 1, 0, 15}, {"fifo-fanout", 0, 0, 16},
-                                    {"no-timing", 0, 0, 17},
+                                    {"no-timing", 0, 0, 17}, {"dump-grad-vort", 0, 0, 18}, {"dump-dvortdt", 0, 0, 19},
                                     {0, 0, 0, 0}};
     int opt;
     while ((opt = getopt_long(argc, args, "I:O:i:s:f:", lopts, NULL)) != EOF) {      // main.cpp:68-80, main-shallow-water.cpp:75-95
@@ -464,12 +503,15 @@ int main(int argc, char *args[])
         case 15: cfg.comm_timeout = atol(optarg); break;
         case 16: cfg.fanout = true; break;
         case 17: cfg.timing = false; break;
+        case 18: cfg.dump_grad = true; break;            // main.cpp:156-162,170-176 (#ifdef OUTPUT_GRAD_VORT; configuration.hpp:4-5 defines only OUTPUT_PSI and OUTPUT_WIND)
+        case 19: cfg.dump_dvortdt = true; break;         // main.cpp:229-235 (#ifdef OUTPUT_DVORTDT)
         }
     }
     if (cfg.world < 1 || cfg.rank < 0 || cfg.rank >= cfg.world || (cfg.world > 1 && !cfg.threads && cfg.comm_file.empty()) ||
         cfg.token.size() >= fbcomm::TOKEN_BYTES) {
         fprintf(stderr, "usage: ... --world P --rank r --comm-file FILE [--launch-token T]   (or --world P --ranks-as-threads)\n"); return 2;
     }
+    if ((cfg.dump_grad || cfg.dump_dvortdt) && cfg.world > 1) { fprintf(stderr, "--dump-grad-vort / --dump-dvortdt: one GPU only\n"); return 2; }
     if (cfg.total_steps < 0) cfg.total_steps = (int)(60 * 60 / cfg.dt);              // configuration.hpp:36
     float dx = 0, dy = 0;                                                            // printed before being set, main.cpp:89-90
 
