@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- RK4 steps/s of the pseudospectral barotropic-vorticity hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: under torch.distributed.run --nproc-per-node N as the contract says, or from a plain shell -- then this process starts that job
+  itself as a child, before touching a GPU, and passes rank 0's line on)
 
 One "step" = one RK4 step (4 stages = 16 c2r + 4 r2c 2-D FFTs + all pointwise work of
 main.cpp:286-317) of the synthetic workload below, state resident in HBM.  Prints ONE JSON line.
@@ -9,7 +11,11 @@ main.cpp:286-317) of the synthetic workload below, state resident in HBM.  Print
 Workload at N=1: BASELINE.json configs[2] -- 4096x4096 Kuo2004 initial field, fp32,
 dt = 3*1024/4096 s (the reference's dt=3 s is unstable above N~2300).
 For N>1 the same grid is split into x-row / ky-column slabs (strong scaling; the engine drives the
-RCCL all-to-all transposes itself, csrc/fb_slab_driver.h), see DESIGN.md section 6.
+RCCL all-to-all transposes itself, csrc/fb_slab_driver.h), see DESIGN.md section 6.  The N>1 line also carries: `rccl_ranks`
+(ncclCommCount as every rank's communicator reports it), `devices` (HIP ordinals), `predicted` (the model of DESIGN.md section 6
+beside the measured `value`), `one_gpu_same_grid_steps_per_s` / `vs_1gpu_same_grid` (rank 0 alone on the same grid in the same job)
+and `configs_run`: at N = 4 also 8192^2 gaussian (BASELINE configs[3]), at N = 8 also 16384^2 source-forced (configs[4]), each with
+its own single-GPU rate.  At N=1 a `driver` leg times the C++ drop-in driver itself (1000 steps, record_step 100).
 
 Roofline conventions: `roofline.achieved` uses the contract's algorithmic bytes (SURVEY.md
 8(d): 8 N^2 per 1-D pass over a field, 320 N^2 per step); next to it the line carries the bytes the kernels really
@@ -299,7 +305,7 @@ def slab_run(X, torch, dist, slab, args, n, kind, with_source, dt, rank, world):
     every.sort(key=lambda d: d["rank"])
     counts = [d["comm_ranks"] for d in every]
     rccl_ranks = counts[0] if (min(counts) == max(counts) and counts[0] > 0) else None
-    if args.backend == "nccl" and rccl_ranks != world:
+    if args.backend == "nccl" and max(counts) > 0 and rccl_ranks != world:      # (-1 everywhere: this RCCL build lacks ncclCommCount; reported as null)
         raise SystemExit("bench.py: ncclCommCount reports %r on the ranks, expected %d everywhere" % (counts, world))
     v0_local = torch.from_numpy(slab.local_rows(X.make_field(kind, n), rank, world)).cuda()
     src_local = torch.from_numpy(slab.local_rows(X.make_source_kuo2004(n), rank, world)).cuda() if with_source else None
