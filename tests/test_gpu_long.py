@@ -1,6 +1,7 @@
 """BASELINE configs 4 and 5 at FULL size over a horizon, against committed oracle fixtures.
 
-The CPU side is tests/golden/oracle_8192_step300.npz and oracle_16384_src_step12.npz: the oracle (oracle/fb_oracle.c, the C
+The CPU side is tests/golden/oracle_8192_step1000.npz (round 4: the north-star horizon), oracle_16384_src_step52.npz (round 4: across the
+source's on and off) and oracle_16384_src_step12.npz (round 3: a short on/off cycle): the oracle (oracle/fb_oracle.c, the C
 restatement of main.cpp:146-317 / main-shallow-water.cpp:277-338) run in the build container by
 tests/golden/make_long_fixtures.py -- sub-sampled fields plus the full-field L2 norm and sum at the recorded steps.  Held to
 them, at the north-star bar of 1e-5 relative L2: the default single-GPU path (8192^2: k_rowh2 + k_col_full<., 2>; 16384^2:
@@ -71,17 +72,20 @@ def _ranks_run(n, world, dt, v0, script, sub):
     return snaps
 
 
-def test_config4_8192_gaussian_300_steps_against_the_oracle_fixture():
-    """BASELINE configs[3]: 8192 x 8192 gaussian vortex (makefield-gaussian.cpp:14-31), dt = 0.375 s, steps 10 / 100 / 300 of
-    main.cpp:259-317: the default single-GPU path and the 4-rank ky-slab schedule, each against the oracle fixture."""
+def test_config4_8192_gaussian_1000_steps_against_the_oracle_fixture():
+    """BASELINE configs[3] to the north-star horizon: 8192 x 8192 gaussian vortex (makefield-gaussian.cpp:14-31), dt = 0.375 s, steps
+    10 / 100 / 300 / 600 / 1000 of main.cpp:259-317: the default single-GPU path and the 4-rank ky-slab schedule, each against the oracle
+    fixture (tests/golden/oracle_8192_step1000.npz: 5.5 h of the build container's CPU; round 3 pinned 300 steps)."""
     import xlab_fftbarotropic_amd as X
-    G = np.load(os.path.join(GOLD, "oracle_8192_step300.npz"))
+    G = np.load(os.path.join(GOLD, "oracle_8192_step1000.npz"))
     n, dt, sub = 8192, 0.375, 32
+    marks = sorted(int(k[len("l2_step"):]) for k in G.files if k.startswith("l2_step"))
+    assert marks[-1] == 1000 and 300 in marks, marks                 # the committed fixture reaches the north-star horizon
     v0 = X.make_field("gaussian", n)
     m = X.Model(n, n, dt=dt)
     m.set_vort(v0)
     done, worst = 0, 0.0
-    for upto in (10, 100, 300):
+    for upto in marks:
         m.step(upto - done)
         done = upto
         v = m.vort()
@@ -89,10 +93,56 @@ def test_config4_8192_gaussian_300_steps_against_the_oracle_fixture():
         worst = max(worst, _check("one GPU", v[::sub, ::sub].cpu().numpy(), l2, tot, G, sub, upto))
         del v
     del m
-    snaps = _ranks_run(n, 4, dt, v0, [(10, "keep"), (90, "keep"), (200, "keep")], sub)
-    for (vs, l2, tot), upto in zip(snaps, (10, 100, 300)):
+    snaps = _ranks_run(n, 4, dt, v0, [(b - a, "keep") for a, b in zip([0] + marks[:-1], marks)], sub)
+    for (vs, l2, tot), upto in zip(snaps, marks):
         worst = max(worst, _check("4 ranks", vs, l2, tot, G, sub, upto))
-    print("config 4, 300 steps: worst rel L2 against the oracle fixture %.2e" % worst)
+    print("config 4, %d steps: worst rel L2 against the oracle fixture %.2e" % (marks[-1], worst))
+
+
+def test_config5_16384_source_forced_52_steps_across_the_sources_on_and_off():
+    """BASELINE configs[4] over 52 steps: 16384 x 16384 Kuo2004 field through the source-forced loop (main-shallow-water.cpp:277-338), the
+    producer's cake (vort_src_input.cpp:35-46) handed over before step 2 and the field of zeros before step 27 (:52-55, the producer's
+    beg_step / end_step shifted into the window); dt = 0.1875 s; records after steps 12, 26, 27, 40, 52 -- i.e. with the source in force,
+    on its last step, on the first step without it and well after.  The default single-GPU path and the 8-rank schedule against
+    tests/golden/oracle_16384_src_step52.npz."""
+    import xlab_fftbarotropic_amd as X
+    G = np.load(os.path.join(GOLD, "oracle_16384_src_step52.npz"))
+    n, dt, sub = 16384, 0.1875, 64
+    on, off = int(G["on_step"]), int(G["off_step"])
+    marks = sorted(int(k[len("l2_step"):]) for k in G.files if k.startswith("l2_step"))
+    assert (on, off) == (2, 27) and marks[-1] >= 50 and off - 1 in marks and off in marks, (on, off, marks)
+    v0 = X.make_field("kuo2004", n)
+    src = X.make_source_kuo2004(n)
+    m = X.Model(n, n, dt=dt)
+    m.set_vort(v0)
+    worst = 0.0
+    for step in range(1, marks[-1] + 1):
+        if step == on:
+            m.set_source(src)
+        elif step == off:
+            m.set_source(np.zeros((n, n), dtype=np.float32))
+        m.step(1)
+        if step in marks:
+            v = m.vort()
+            l2, tot = _stats(v)
+            worst = max(worst, _check("one GPU", v[::sub, ::sub].cpu().numpy(), l2, tot, G, sub, step))
+            del v
+    del m
+    # the same schedule as segments for the ranks: (steps, source handed over BEFORE the segment)
+    cuts = sorted(set([on - 1, off - 1] + marks))                  # segment ends; a source change starts a new segment
+    script, prev = [], 0
+    for c in cuts:
+        if c <= prev:
+            continue
+        first = prev + 1                                          # first step of this segment
+        script.append((c - prev, src if first == on else (None if first == off else "keep")))
+        prev = c
+    snaps = _ranks_run(n, 8, dt, v0, script, sub)
+    ends = [c for c in cuts if c > 0]
+    for (vs, l2, tot), step in zip(snaps, ends):
+        if step in marks:
+            worst = max(worst, _check("8 ranks", vs, l2, tot, G, sub, step))
+    print("config 5, %d steps: worst rel L2 against the oracle fixture %.2e" % (marks[-1], worst))
 
 
 def test_config5_16384_source_forced_12_steps_against_the_oracle_fixture():
