@@ -132,6 +132,41 @@ def oracle16384_52():
     print("done in %.0f s" % (time.time() - t0))
 
 
+def _strip(nx, ny, dt, tag):
+    """1000 steps on a strip-shaped grid: the cheap way to give the kernels that carry nx = 16384 (k_col_strided<128>, k_col_mid<128>) and
+    ny = 16384 (k_rowh<2>) a horizon of 1000 steps (the 16384^2 grid itself costs the oracle 100 s of this container per step).  Elliptic
+    vortex (makefield-elliptic-vortex.cpp:14-52, max wind ~ 83 m/s), dt = 0.375 s: U k_max dt ~ 1.8 at the largest retained wavenumber
+    of the long direction (RK4 limit 2.8)."""
+    import oracle_py as O
+    m = O.Model(nx, ny, dt=dt)
+    m.set_vort(O.make_field("elliptic", nx, ny))
+    sx, sy = max(1, nx // 256), max(1, ny // 256)
+    out = {"note": np.array("oracle/liboracle.so, %d x %d elliptic vortex, nu=6.5, L=600 km, dt=%g s; vort[::%d, ::%d], l2 = sqrt(sum(vort^2)) in "
+                            "float64; made by tests/golden/make_long_fixtures.py %s" % (nx, ny, dt, sx, sy, tag)),
+           "sub": np.array([sx, sy], dtype=np.int64), "dt": np.float64(dt)}
+    done, t0 = 0, time.time()
+    for upto in (100, 500, 1000):
+        while done < upto:
+            m.step(50)
+            done += 50
+            print("step %d  %.0f s" % (done, time.time() - t0), flush=True)
+        v = m.vort()
+        v64 = v.astype(np.float64)
+        out["vort_step%d" % upto] = v[::sx, ::sy].copy()
+        out["l2_step%d" % upto] = np.float64(np.sqrt((v64 * v64).sum()))
+        out["sum_step%d" % upto] = np.float64(v64.sum())
+        np.savez_compressed(os.path.join(HERE, "oracle_%dx%d_step1000.npz" % (nx, ny)), **out)
+    print("done in %.0f s" % (time.time() - t0))
+
+
+def strip_cols():
+    _strip(16384, 64, 0.375, "strip_cols")
+
+
+def strip_rows():
+    _strip(128, 16384, 0.375, "strip_rows")
+
+
 def oracle16384():
     import oracle_py as O
     n, dt, sub, L = 16384, 0.1875, 64, 600000.0
@@ -180,4 +215,4 @@ def fp64_1024():
 
 if __name__ == "__main__":
     {"oracle4096": oracle4096, "fp64_1024": fp64_1024, "oracle8192": oracle8192, "oracle16384": oracle16384,
-     "oracle8192_1000": oracle8192_1000, "oracle16384_52": oracle16384_52}[sys.argv[1]]()
+     "oracle8192_1000": oracle8192_1000, "oracle16384_52": oracle16384_52, "strip_cols": strip_cols, "strip_rows": strip_rows}[sys.argv[1]]()

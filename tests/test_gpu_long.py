@@ -174,3 +174,28 @@ def test_config5_16384_source_forced_12_steps_against_the_oracle_fixture():
     for (vs, l2, tot), step in zip(snaps, (1, 5, 8, 12)):
         worst = max(worst, _check("8 ranks", vs, l2, tot, G, sub, step))
     print("config 5, 12 steps: worst rel L2 against the oracle fixture %.2e" % worst)
+
+
+@pytest.mark.parametrize("nx,ny", [(16384, 64), (128, 16384)])
+def test_strip_grids_give_the_16384_kernels_a_1000_step_horizon(nx, ny):
+    """The kernels that carry BASELINE configs[4] -- k_col_strided<128> and k_col_mid<128> (nx = 16384), k_rowh<2> (ny = 16384) -- over the
+    north-star horizon of 1000 RK4 steps (main.cpp:259-317), on strip-shaped grids the oracle can afford (tests/golden/
+    oracle_16384x64_step1000.npz, oracle_128x16384_step1000.npz: elliptic vortex, dt = 0.375 s; the square 16384^2 grid is pinned over 52
+    steps above).  Bar: 1e-5 relative L2 at steps 100 / 500 / 1000, and the full-field L2 norm and sum."""
+    import ref_numpy as R
+    import xlab_fftbarotropic_amd as X
+    G = np.load(os.path.join(GOLD, "oracle_%dx%d_step1000.npz" % (nx, ny)))
+    sx, sy = (int(v) for v in G["sub"])
+    m = X.Model(nx, ny, dt=float(G["dt"]))
+    m.set_vort(X.make_field("elliptic", nx, ny))
+    done, worst = 0, 0.0
+    for upto in (100, 500, 1000):
+        m.step(upto - done)
+        done = upto
+        v = m.vort()
+        l2, tot = _stats(v)
+        err = R.rel_l2(v[::sx, ::sy].cpu().numpy(), G["vort_step%d" % upto])
+        worst = max(worst, err)
+        assert err < 1e-5, (nx, ny, upto, err)
+        assert abs(l2 / float(G["l2_step%d" % upto]) - 1) < 1e-5 and abs(tot / float(G["sum_step%d" % upto]) - 1) < 1e-5, (nx, ny, upto)
+    print("%d x %d, 1000 steps: worst rel L2 against the oracle fixture %.2e" % (nx, ny, worst))

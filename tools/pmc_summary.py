@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc output: per kernel, the average of every counter over its launches; and, under "<counter>_big" /
-"launches_big", the same over the kernel's LARGE launches only (one set per kernel: launches whose FETCH_SIZE is >= 0.6 x the kernel's
-maximum, matched across the counter passes by launch order): k_col_strided<N1, 1> runs
+"launches_big", the same over the kernel's LARGE launches only (one criterion per kernel for every counter: the launch's grid size >= 0.6 x
+the kernel's largest grid): k_col_strided<N1, 1> runs
 both as a four-field launch per RK stage and as single-field launches of set/get, and bench.py prices the former.
 usage: pmc_summary.py <dir-with-*_counter_collection.csv> [more dirs...]  -> JSON on stdout"""
 import csv, glob, json, os, re, sys
@@ -12,29 +12,36 @@ def short(name):
     return re.sub(r"\(.*$", "", name)
 
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
-vals = defaultdict(lambda: defaultdict(dict))              # kernel -> counter -> {dispatch key: value}
+rows = defaultdict(lambda: defaultdict(list))              # kernel -> counter -> [(grid size or None, value), ...]
 for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        order = defaultdict(int)
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
                 k, c = short(row["Kernel_Name"]), row["Counter_Name"]
                 a = acc[k][c]
                 a[0] += float(row["Counter_Value"]); a[1] += 1
-                # counters come from separate passes of the same command: the n-th launch of a kernel in one pass is the n-th in the other
-                order[(k, c)] += 1
-                vals[k][c][order[(k, c)]] = vals[k][c].get(order[(k, c)], 0.0) + float(row["Counter_Value"])
+                g = row.get("Grid_Size")
+                rows[k][c].append((float(g) if g not in (None, "") else None, float(row["Counter_Value"])))
 out = {k: {c: v[0] / v[1] for c, v in cs.items()} | {"launches": max(v[1] for v in cs.values())} for k, cs in acc.items()}
-for k, cs in vals.items():
-    # ONE set of large launches per kernel, chosen by a reference counter (the bytes read, else the first counter) and keyed by launch
-    # order; every counter is averaged over that same set (a per-counter threshold could pick different launches)
-    ref = "FETCH_SIZE" if "FETCH_SIZE" in cs else sorted(cs)[0]
-    top = max(cs[ref].values())
-    big = sorted(i for i, x in cs[ref].items() if x >= 0.6 * top)
-    out[k]["launches_big"] = len(big)
-    out[k]["big_selected_by"] = ref
+for k, cs in rows.items():
+    # The LARGE launches of a kernel are chosen by ONE criterion for every counter: the launch's grid size (>= 0.6 x the kernel's largest
+    # grid), which every pass records identically -- the passes are separate processes whose launch COUNTS can differ (the pitch probe of
+    # fb_create is time-based), so neither dispatch ids nor launch order match across them.  Only where the grids do not
+    # tell the launches apart does the counter's own value decide (>= 0.6 x its maximum), as in round 3.
+    grids = [g for v in cs.values() for g, _ in v if g is not None]
+    by_grid = bool(grids) and min(grids) < 0.6 * max(grids)
+    out[k]["big_selected_by"] = "Grid_Size" if by_grid else "counter value"
+    counts = []
     for c, v in cs.items():
-        sel = [v[i] for i in big if i in v]
+        if by_grid:
+            sel = [x for g, x in v if g is not None and g >= 0.6 * max(grids)]
+        else:
+            top = max(x for _, x in v)
+            sel = [x for _, x in v if x >= 0.6 * top]
         if sel:
             out[k][c + "_big"] = sum(sel) / len(sel)
+            counts.append(len(sel))
+    out[k]["launches_big"] = max(counts) if counts else 0
+    if counts and min(counts) != max(counts):
+        out[k]["launches_big_per_counter"] = counts           # the passes saw different numbers of large launches (reported, not hidden)
 json.dump(out, sys.stdout, indent=1, sort_keys=True)

@@ -16,6 +16,7 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o p -
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o p --output-format csv -- python3 bench.py --grid $n --steps 3 --warmup 1 --cpu-steps 0 --driver-steps 0 > $out/write.log 2>&1 &&
 timeout -k 10 900 python3 bench.py --grid $n --cpu-steps $cpu > $out/bench.json 2> $out/bench.err
 python3 tools/pmc_summary.py $out/fetch $out/write > $out/pmc.json
+find $out/fetch -name "*counter_collection.csv" | head -1 | xargs -I{} head -3 {} > $out/pmc_csv_head.txt
 find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
 # the raw traces are large: keep the summaries only
 rm -rf $out/stats $out/fetch $out/write
