@@ -256,7 +256,17 @@ def test_transport_selftests():
         bad = C.c_size_t(123)
         X.package.binding.check(L.fb_slab_transport_selftest(m._h, 1 << 20, C.byref(bad)))
         assert bad.value == 0
+        # what bench.py prints as rccl_ranks / devices comes from here: ncclCommCount, ncclCommUserRank and ncclCommCuDevice as the REAL
+        # communicator answers them (the three symbols are dlsym'd from whichever RCCL the process has loaded; -1 would mean "not found")
+        import torch
+        info = m.transport_info()
+        assert info["name"] == "rccl" and info["comm_ranks"] == 1 and info["comm_rank"] == 0, info
+        assert info["hip_device"] == torch.cuda.current_device() and info["comm_device"] == info["hip_device"], info
         m.close()
+        plain = S.EngineSlab(256, rank=0, world=1)                  # nothing connected: no communicator to ask
+        i0 = plain.transport_info()
+        assert i0["name"] == "none" and i0["comm_ranks"] == -1 and i0["hip_device"] == torch.cuda.current_device(), i0
+        plain.close()
     finally:
         os.environ.pop("FB_RCCL_SELF", None)
 

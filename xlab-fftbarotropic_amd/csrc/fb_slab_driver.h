@@ -205,12 +205,13 @@ extern "C" int fb_slab_info(fb_slab *s, int *rows_local, int *cols_active, int *
 extern "C" int fb_slab_transport_info(fb_slab *s, char *name, size_t cap, int *comm_ranks, int *comm_rank, int *comm_device, int *hip_device)
 {
     if (!s) return fail(FB_EINVAL, "slab NULL");
-    const char *nm = s->c->world == 1 ? "none" : (s->connected && s->tp.name ? s->tp.name : "unconnected");
+    // a transport that is connected is named, also on one rank (the one-GPU test of the RCCL call path connects one); "none" = one rank, nothing connected
+    const char *nm = (s->tp.alltoall && s->tp.name) ? s->tp.name : (s->c->world == 1 ? "none" : "unconnected");
     if (name && cap) { strncpy(name, nm, cap - 1); name[cap - 1] = 0; }
     if (comm_ranks) *comm_ranks = -1;
     if (comm_rank) *comm_rank = -1;
     if (comm_device) *comm_device = -1;
-    if (s->connected && s->tp.info) s->tp.info(s->tp.self, comm_ranks, comm_rank, comm_device);
+    if (s->tp.alltoall && s->tp.info) s->tp.info(s->tp.self, comm_ranks, comm_rank, comm_device);
     if (hip_device) { int d = -1; if (hipGetDevice(&d) != hipSuccess) d = -1; *hip_device = d; }
     return FB_OK;
 }
