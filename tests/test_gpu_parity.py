@@ -618,6 +618,80 @@ def test_three_kernel_path_is_bitwise_independent_of_the_pitch_4096():
             assert np.array_equal(probed[k].view(np.uint32), r[k].view(np.uint32)), (tag, k)
 
 
+@pytest.mark.parametrize("nx,ny", [(16384, 64), (128, 16384)])
+def test_long_column_and_long_row_kernels_are_bitwise_independent_of_the_pitch(X, nx, ny):
+    """The same property for the kernels that carry nx = 16384 (k_col_strided<128>, k_col_mid<128>: 128-row wave tiles) and ny = 16384
+    (k_rowh<2>), cheaply, on strip grids: pitches minimum + 0 / 16 / 48 columns -- vort() and spectrum() bit for bit after 3 steps of a
+    never-dealiased noise state with a source.  NOTE what this does not do: the timing probe never runs on grids this small
+    (autotune_pitch returns early below 32 MiB per field), so the default run and FB_NO_PITCH_TUNE=1 use the minimal pitch here and only
+    the FIXED pitches differ; the probe's own choice is compared in test_pitch_probe_choice_is_bitwise_neutral_16384 below.  The switches
+    are read when the context is created, so one process can hold the models one after the other."""
+    rng = np.random.default_rng(41)
+    v0 = (rng.standard_normal((nx, ny)) * 1e-4).astype(np.float32) + X.make_field("elliptic", nx, ny)
+    src = (rng.standard_normal((nx, ny)) * 1e-9).astype(np.float32)
+    keys = ("FB_PITCH_EXTRA", "FB_NO_PITCH_TUNE", "FB_PITCH_TUNE")
+    saved = {k: os.environ.pop(k, None) for k in keys}
+
+    def run(env):
+        os.environ.update(env)
+        try:
+            m = X.Model(nx, ny, dt=0.375)
+            m.set_vort(v0)
+            m.set_source(src)
+            m.step(3)
+            return m.vort().cpu().numpy(), m.spectrum().cpu().numpy()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    try:
+        probed = run({})
+        for env in ({"FB_PITCH_EXTRA": "0"}, {"FB_PITCH_EXTRA": "1"}, {"FB_PITCH_EXTRA": "3"}, {"FB_NO_PITCH_TUNE": "1"}):
+            got = run(env)
+            for a, b, what in zip(probed, got, ("vort", "spectrum")):
+                assert np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32)), (nx, ny, env, what)
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
+
+
+def test_pitch_probe_choice_is_bitwise_neutral_16384(X, torch):
+    """Where the timing probe really decides: 16384^2 on one GPU (three-kernel x pass, autotune_pitch times the backward strided sub-pass
+    for four candidate pitches when the context is created, so two runs of the same program may compute at different pitches).  The
+    probe's choice against the fixed pitches minimum + 0 and + 48 columns: vort() after 2 source-forced steps, bit for bit, compared on
+    the device (1 GiB per field; no oracle involved -- this is about the pitch, the values are pinned elsewhere)."""
+    n, dt = 16384, 0.1875
+    v0 = X.make_field("kuo2004", n)
+    src = X.make_source_kuo2004(n)
+    keys = ("FB_PITCH_EXTRA", "FB_NO_PITCH_TUNE", "FB_PITCH_TUNE")
+    saved = {k: os.environ.pop(k, None) for k in keys}
+
+    def run(env):
+        os.environ.update(env)
+        try:
+            m = X.Model(n, n, dt=dt)
+            m.set_vort(v0)
+            m.set_source(src)
+            m.step(2)
+            out = m.vort().view(torch.int32).clone()
+            del m
+            torch.cuda.empty_cache()
+            return out
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    try:
+        probed = run({})
+        for env in ({"FB_PITCH_EXTRA": "0"}, {"FB_PITCH_EXTRA": "3"}):
+            got = run(env)
+            assert bool(torch.equal(probed, got)), env
+            del got
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
+
+
 def test_single_pass_and_three_kernel_paths_agree_over_600_steps_4096(R):
     """600 steps of the headline configuration on the default path (k_col_full) and on the three-kernel x pass: the same maths
     with two FFT factorisations stays within the north-star bar of each other at the 1000-step class horizon."""
