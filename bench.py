@@ -362,6 +362,14 @@ def one_gpu_same_grid(X, torch, dist, args, n, kind, with_source, dt, rank):
     return float(t.item()) or None
 
 
+def _driver_breakdown(lines):
+    m = re.search(r"of those ([0-9.]+) s: ([0-9.]+) s stepping, ([0-9.]+) s with a record step holding the compute stream .*?, ([0-9.]+) s between the last "
+                  r"step's end and the last file \(writer tail\), (-?[0-9.]+) s unaccounted", lines[2]) if len(lines) > 2 else None
+    if not m:
+        return None
+    return dict(zip(("wall", "stepping", "record_steps_on_compute_stream", "writer_tail", "unaccounted"), (float(m.group(i)) for i in range(1, 6))))
+
+
 def driver_leg(X, n, kind, with_source, dt, steps, record_step=100):
     """The drop-in C++ driver itself (host/barotropic_main.out: main.cpp:65-328 on the engine) on the same workload, BASELINE.md's stated run:
     `steps` RK4 steps with a record every `record_step` (configuration.hpp:34-36), five record files per record step written by the
@@ -399,6 +407,7 @@ def driver_leg(X, n, kind, with_source, dt, steps, record_step=100):
                 "driver_wall_s": float(m2.group(4)), "record_GB_written": float(m2.group(2)),
                 "writer_busy_s": float(m2.group(5)), "writer_disk_GBs": float(m2.group(6)),
                 "process_wall_s": wall,                                # start-up (context, tables, pitch probe), input read and teardown included
+                "wall_breakdown_s": _driver_breakdown(lines),          # the driver's own account of where the wall time went (third [timing] line)
                 "timing_lines": lines}
     finally:
         shutil.rmtree(d, ignore_errors=True)

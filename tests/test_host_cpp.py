@@ -464,7 +464,12 @@ def test_runtest_example_on_product_binaries_only(tmp_path):
     log = (tmp_path / "log").read_text().split()
     assert len(log) == 12 * 5 and log[:2] == ["output/vort_src_input_step_0.bin", "output/vort_step_0.bin"]
     tl = [ln for ln in res.stderr.splitlines() if ln.startswith("[timing]")]
-    assert len(tl) == 2
+    assert len(tl) == 3
+    m3 = re.search(r"of those ([0-9.]+) s: ([0-9.]+) s stepping, ([0-9.]+) s with a record step holding the compute stream .*?, ([0-9.]+) s between the last "
+                   r"step's end and the last file \(writer tail\), (-?[0-9.]+) s unaccounted", tl[2])
+    assert m3, tl[2]
+    parts = [float(m3.group(i)) for i in range(1, 6)]
+    assert abs(parts[0] - sum(parts[1:])) < 2e-3 and all(x >= -2e-3 for x in parts[1:4])      # the four parts add up to the wall time
     m1 = re.search(r"1200 RK4 steps, 768 x 768 grid, 1 GPU: step loop without the record steps ([0-9.]+) steps/s \(([0-9.]+) ms/step\) = ([0-9.]+) GB/s "
                    r"by 320 N\^2 B/step = ([0-9.]+) of 8000 GB/s", tl[0])
     m2 = re.search(r"with 12 record steps \(([0-9.]+) GB written\): ([0-9.]+) steps/s over ([0-9.]+) s of wall time", tl[1])

@@ -439,14 +439,20 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
         eng->step();                                                                   // main.cpp:286-317
     }
     stamp(t_end);
-    writer.stop();
+    eng->sync();                                                                       // the last step has run ...
+    const auto compute_done = std::chrono::steady_clock::now();
+    writer.stop();                                                                     // ... and now the last record's files are on their way
     const bool feed_done = feed.shutdown();
-    eng->sync();
     must(fb_stream_synchronize(copy), "sync");
     if (timing) {
-        const double wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
-        double gpu_ms = 0.0;
+        const auto wall1 = std::chrono::steady_clock::now();
+        const double wall_s = std::chrono::duration<double>(wall1 - wall0).count();
+        const double tail_s = std::chrono::duration<double>(wall1 - compute_done).count();
+        double gpu_ms = 0.0, rec_ms = 0.0;
         for (size_t k = 0; k < t_beg.size() && k < t_end.size(); ++k) { float ms = 0.0f; must(fb_event_elapsed_ms(t_beg[k], t_end[k], &ms), "elapsed"); gpu_ms += ms; }
+        // what lies BETWEEN the stretches on the compute stream: a record branch from its first event to the one behind its record kernels,
+        // i.e. those kernels plus whatever time the stream sat idle while the host was inside the branch (waiting for the writer, enqueueing)
+        for (size_t k = 0; k + 1 < t_beg.size() && k < t_end.size(); ++k) { float ms = 0.0f; must(fb_event_elapsed_ms(t_end[k], t_beg[k + 1], &ms), "elapsed"); rec_ms += ms; }
         for (void *e : t_beg) fb_event_destroy(e);
         for (void *e : t_end) fb_event_destroy(e);
         if (lead) {
@@ -457,6 +463,10 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
             fprintf(stderr, "[timing] with %d record steps (%.3f GB written%s): %.1f steps/s over %.3f s of wall time; the writer thread was busy %.3f s = %.2f GB/s to %s\n",
                     n_records, writer.bytes * (double)(P > 1 && !cfg.threads ? P : 1) / 1e9, P > 1 && !cfg.threads ? ", all ranks" : (P > 1 ? ", this rank" : ""), steps / wall_s, wall_s, writer.busy_s,
                     writer.busy_s > 0 ? writer.bytes / writer.busy_s / 1e9 : 0.0, cfg.output.c_str());
+            // where the difference between the two rates goes, measured rather than guessed
+            fprintf(stderr, "[timing] of those %.3f s: %.3f s stepping, %.3f s with a record step holding the compute stream (record kernels + idle while the host was in the record branch), "
+                            "%.3f s between the last step's end and the last file (writer tail), %.3f s unaccounted (loop start-up, event bookkeeping)\n",
+                    wall_s, gpu_ms * 1e-3, rec_ms * 1e-3, tail_s, wall_s - gpu_ms * 1e-3 - rec_ms * 1e-3 - tail_s);
             fflush(stderr);
         }
     }
