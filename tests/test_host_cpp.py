@@ -464,7 +464,7 @@ def test_runtest_example_on_product_binaries_only(tmp_path):
     log = (tmp_path / "log").read_text().split()
     assert len(log) == 12 * 5 and log[:2] == ["output/vort_src_input_step_0.bin", "output/vort_step_0.bin"]
     tl = [ln for ln in res.stderr.splitlines() if ln.startswith("[timing]")]
-    assert len(tl) == 3
+    assert len(tl) == 4 and tl[3].startswith("[timing] host time inside the 12 record branches:")
     m3 = re.search(r"of those ([0-9.]+) s: ([0-9.]+) s stepping, ([0-9.]+) s with a record step holding the compute stream .*?, ([0-9.]+) s between the last "
                    r"step's end and the last file \(writer tail\), (-?[0-9.]+) s unaccounted", tl[2])
     assert m3, tl[2]

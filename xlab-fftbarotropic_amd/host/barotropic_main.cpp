@@ -394,6 +394,8 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
     eng->sync();
     const auto wall0 = std::chrono::steady_clock::now();
     int n_records = 0;
+    double host_wait_s = 0.0, host_get_s = 0.0, host_copy_s = 0.0;                     // host time inside the record branch, by part
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     stamp(t_beg);
 
     // The reference can be restarted from any vort_step_N.bin via -i, but always renumbers from 0
@@ -404,12 +406,16 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
         if (record) {                                                                  // main.cpp:266-282 and the stage-0 dumps :181-222
             stamp(t_end);
             ++n_records;
+            auto h0 = std::chrono::steady_clock::now();
             writer.wait_idle();                                                        // pinned buffers are free again
+            host_wait_s += since(h0);
             if (copies_pending) eng->wait(e_copy);                                     // device record buffers are free again
             feed.hold(feed.cur);                                                       // vort_src as of this step (dumped BEFORE this step's read)
             writer.src = feed.cur >= 0 ? feed.pin[feed.cur] : zeros.data();
             writer.src_buf = feed.cur;
+            h0 = std::chrono::steady_clock::now();
             eng->get(d_out[0], d_out[1], d_out[2], d_out[3]);
+            host_get_s += since(h0);
             if (cfg.dump_grad || cfg.dump_dvortdt) {
                 // vort_src on the device: d_in holds the source in force once one has been uploaded (before that: zeros = NULL)
                 eng->get_debug(d_out[4], d_out[5], d_out[6], d_out[2], d_out[3], feed.cur >= 0 ? d_in : nullptr);
@@ -417,7 +423,9 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
             }
             eng->record(e_rec);
             must(fb_stream_wait_event(copy, e_rec), "wait");
+            h0 = std::chrono::steady_clock::now();
             for (int i = 0; i < 7; ++i) if (use[i]) must(fb_memcpy_d2h_async(copy, writer.h[i], d_out[i], floats * sizeof(float)), "d2h");
+            host_copy_s += since(h0);
             must(fb_event_record(e_copy, copy), "record");
             copies_pending = true;
             writer.submit(step);
@@ -467,6 +475,8 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
             fprintf(stderr, "[timing] of those %.3f s: %.3f s stepping, %.3f s with a record step holding the compute stream (record kernels + idle while the host was in the record branch), "
                             "%.3f s between the last step's end and the last file (writer tail), %.3f s unaccounted (loop start-up, event bookkeeping)\n",
                     wall_s, gpu_ms * 1e-3, rec_ms * 1e-3, tail_s, wall_s - gpu_ms * 1e-3 - rec_ms * 1e-3 - tail_s);
+            fprintf(stderr, "[timing] host time inside the %d record branches: %.3f s waiting for the writer thread, %.3f s enqueueing the record kernels, %.3f s in the D2H copy calls\n",
+                    n_records, host_wait_s, host_get_s, host_copy_s);
             fflush(stderr);
         }
     }
