@@ -199,7 +199,7 @@ struct RecordWriter {
     const float *src = nullptr; int src_buf = -1; SourceFeed *feed = nullptr;          // vort_src as of the record step
     std::string output; FILE *log_fd = nullptr; size_t floats = 0;
     bool whole = true, lead = true; off_t off = 0;                                     // whole file (writeField) or this rank's byte range
-    double busy_s = 0.0; size_t bytes = 0;                                             // time spent writing and what was written ([timing] summary)
+    double busy_s = 0.0, slowest_s = 0.0; size_t bytes = 0;                            // time spent writing (total, slowest record) and what was written ([timing] summary)
     void start() { th = std::thread([this] { run(); }); }
     void run()
     {
@@ -227,7 +227,9 @@ struct RecordWriter {
                 if (lead) { fprintf(log_fd, "%s\n", fn); fflush(log_fd); }
             }
             if (feed) feed->release(src_buf);
-            busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            const double this_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            busy_s += this_s;
+            if (this_s > slowest_s) slowest_s = this_s;
             bytes += items.size() * floats * sizeof(float);
             lk.lock();
             has_job = false;
@@ -475,8 +477,11 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
             fprintf(stderr, "[timing] of those %.3f s: %.3f s stepping, %.3f s with a record step holding the compute stream (record kernels + idle while the host was in the record branch), "
                             "%.3f s between the last step's end and the last file (writer tail), %.3f s unaccounted (loop start-up, event bookkeeping)\n",
                     wall_s, gpu_ms * 1e-3, rec_ms * 1e-3, tail_s, wall_s - gpu_ms * 1e-3 - rec_ms * 1e-3 - tail_s);
-            fprintf(stderr, "[timing] host time inside the %d record branches: %.3f s waiting for the writer thread, %.3f s enqueueing the record kernels, %.3f s in the D2H copy calls\n",
-                    n_records, host_wait_s, host_get_s, host_copy_s);
+            // The host runs a stretch ahead of the GPU and then waits here for the previous record's files; the compute stream only runs dry
+            // when ONE record's files take longer than the stretch between two records minus its D2H copies (the slowest record tells).
+            fprintf(stderr, "[timing] host time inside the %d record branches: %.3f s waiting for the writer thread, %.3f s enqueueing the record kernels, %.3f s in the D2H copy calls; "
+                            "slowest record %.3f s to write, a stretch between records is %.3f s of stepping\n",
+                    n_records, host_wait_s, host_get_s, host_copy_s, writer.slowest_s, n_records > 0 ? gpu_ms * 1e-3 * cfg.record_step / steps : 0.0);
             fflush(stderr);
         }
     }
