@@ -56,6 +56,7 @@ struct Config {
     int world = 1, rank = 0; bool threads = false, fanout = false;
     long comm_max_age = 60, comm_timeout = 600;
     bool timing = true;                                                            // the [timing] summary on stderr (--no-timing: off)
+    int record_buffers = 0;                                                        // sets of pinned record buffers: 0 = by size (two while a set is <= 1 GiB), 1, 2
     bool dump_grad = false, dump_dvortdt = false;                                  // the OUTPUT_GRAD_VORT / OUTPUT_DVORTDT blocks of main.cpp:156-162,170-176,229-235 as run-time options
 };
 
@@ -191,12 +192,18 @@ struct SourceFeed {
 
 // ---- the record path: main.cpp:266-282 and the stage-0 dumps :181-222, written by a thread of its own ---------------------------
 struct RecordWriter {
+    // Up to TWO sets of pinned buffers, each with the event behind its D2H copies: the step loop hands a record over and goes on; it has
+    // to wait only when BOTH sets are still with the writer, i.e. for the record before last.  With one set it waited for the previous
+    // record's files at every record step, and one slow record -- measured: 85-96 ms for 336 MB where the average is 50 ms and the stretch
+    // between two records 84 ms -- left the compute stream dry (1119-1155 against 1190 steps/s at 4096^2).
+    struct Job { int step, set; const float *src; int src_buf; };
     std::thread th; std::mutex mu; std::condition_variable cv;
-    bool has_job = false, quit = false; int step = 0;
-    void *e_copy = nullptr; float *h[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::deque<Job> jobs; bool writing = false, quit = false;
+    int nsets = 1; bool set_free[2] = {true, true};
+    void *e_copy[2] = {nullptr, nullptr}; float *h[2][7] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
     // what a record step writes, in the reference's order (main.cpp:266-282, then the stage-0 dumps :156-235): name and buffer (-1 = vort_src)
     std::vector<std::pair<const char *, int> > items;
-    const float *src = nullptr; int src_buf = -1; SourceFeed *feed = nullptr;          // vort_src as of the record step
+    SourceFeed *feed = nullptr;                                                        // vort_src as of the record step is held until written
     std::string output; FILE *log_fd = nullptr; size_t floats = 0;
     bool whole = true, lead = true; off_t off = 0;                                     // whole file (writeField) or this rank's byte range
     double busy_s = 0.0, slowest_s = 0.0; size_t bytes = 0;                            // time spent writing (total, slowest record) and what was written ([timing] summary)
@@ -205,16 +212,18 @@ struct RecordWriter {
     {
         for (;;) {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [this] { return has_job || quit; });
-            if (!has_job && quit) return;
-            const int st = step;
+            cv.wait(lk, [this] { return !jobs.empty() || quit; });
+            if (jobs.empty() && quit) return;
+            const Job job = jobs.front();
+            jobs.pop_front();
+            writing = true;
             lk.unlock();
-            must(fb_event_synchronize(e_copy), "record: wait for copies");
+            must(fb_event_synchronize(e_copy[job.set]), "record: wait for copies");
             const auto w0 = std::chrono::steady_clock::now();
             char fn[1024];
             for (size_t i = 0; i < items.size(); ++i) {                                // main.cpp:268-278, :156-235
-                snprintf(fn, sizeof fn, "%s/%s_step_%d.bin", output.c_str(), items[i].first, st);
-                const float *data = items[i].second < 0 ? src : h[items[i].second];
+                snprintf(fn, sizeof fn, "%s/%s_step_%d.bin", output.c_str(), items[i].first, job.step);
+                const float *data = items[i].second < 0 ? job.src : h[job.set][items[i].second];
                 if (whole) must(fb_write_field(fn, data, floats), "writeField");
                 else {
                     const int fd = open(fn, O_WRONLY | O_CREAT, 0644);
@@ -226,18 +235,28 @@ struct RecordWriter {
                 }
                 if (lead) { fprintf(log_fd, "%s\n", fn); fflush(log_fd); }
             }
-            if (feed) feed->release(src_buf);
+            if (feed) feed->release(job.src_buf);
             const double this_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
             busy_s += this_s;
             if (this_s > slowest_s) slowest_s = this_s;
             bytes += items.size() * floats * sizeof(float);
             lk.lock();
-            has_job = false;
+            writing = false;
+            set_free[job.set] = true;
             cv.notify_all();
         }
     }
-    void wait_idle() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return !has_job; }); }
-    void submit(int st) { { std::lock_guard<std::mutex> lk(mu); step = st; has_job = true; } cv.notify_all(); }
+    // a set of pinned buffers the writer is done with (blocks while every set is still queued or being written)
+    int acquire()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        int got = -1;
+        cv.wait(lk, [&] { for (int i = 0; i < nsets; ++i) if (set_free[i]) { got = i; return true; } return false; });
+        set_free[got] = false;
+        return got;
+    }
+    void submit(const Job &j) { { std::lock_guard<std::mutex> lk(mu); jobs.push_back(j); } cv.notify_all(); }
+    void wait_idle() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return jobs.empty() && !writing; }); }
     void stop() { wait_idle(); { std::lock_guard<std::mutex> lk(mu); quit = true; } cv.notify_all(); if (th.joinable()) th.join(); }
 };
 
@@ -338,9 +357,9 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
     const size_t floats = (size_t)(N / P) * N;                                         // this rank's share of a field (all of it on one GPU)
     const off_t off = (off_t)rank * floats * sizeof(float);
     Engine *eng = P == 1 ? (Engine *)new SingleEngine(cfg) : (Engine *)new SlabEngine(cfg, rank, hub);
-    void *copy = nullptr, *e_rec = nullptr, *e_copy = nullptr, *e_h2d = nullptr, *e_src = nullptr;
+    void *copy = nullptr, *e_rec = nullptr, *e_h2d = nullptr, *e_src = nullptr;
     must(fb_stream_create(&copy), "stream");
-    for (void **e : {&e_rec, &e_copy, &e_h2d, &e_src}) must(fb_event_create(e), "event");
+    for (void **e : {&e_rec, &e_h2d, &e_src}) must(fb_event_create(e), "event");
     // record buffers 0..3 = vort, psi, u, v; 4, 5 = dvortdx, dvortdy (--dump-grad-vort); 6 = dvortdt (--dump-dvortdt)
     const bool use[7] = {true, true, true, true, cfg.dump_grad, cfg.dump_grad, cfg.dump_dvortdt};
     float *d_in = nullptr, *d_out[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -348,21 +367,27 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
     for (int i = 0; i < 7; ++i) if (use[i]) must(fb_malloc((void **)&d_out[i], floats * sizeof(float)), "fb_malloc");
 
     RecordWriter writer;
-    for (int i = 0; i < 7; ++i) if (use[i]) must(fb_malloc_host((void **)&writer.h[i], floats * sizeof(float)), "fb_malloc_host");
+    size_t set_bytes = 0;
+    for (int i = 0; i < 7; ++i) if (use[i]) set_bytes += floats * sizeof(float);
+    writer.nsets = cfg.record_buffers == 1 || cfg.record_buffers == 2 ? cfg.record_buffers : (set_bytes <= ((size_t)1 << 30) ? 2 : 1);
+    for (int b = 0; b < writer.nsets; ++b) {
+        must(fb_event_create(&writer.e_copy[b]), "event");
+        for (int i = 0; i < 7; ++i) if (use[i]) must(fb_malloc_host((void **)&writer.h[b][i], floats * sizeof(float)), "fb_malloc_host");
+    }
     writer.items = {{"vort_src_input", -1}, {"vort", 0}};                              // main.cpp:268-278
     if (cfg.dump_grad) { writer.items.push_back({"dvortdx", 4}); writer.items.push_back({"dvortdy", 5}); }   // main.cpp:156-162,170-176
     writer.items.push_back({"psi", 1}); writer.items.push_back({"u", 2}); writer.items.push_back({"v", 3});   // main.cpp:181-222
     if (cfg.dump_dvortdt) writer.items.push_back({"dvortdt", 6});                      // main.cpp:229-235
-    writer.e_copy = e_copy; writer.output = cfg.output; writer.log_fd = log_fd; writer.floats = floats;
+    writer.output = cfg.output; writer.log_fd = log_fd; writer.floats = floats;
     writer.whole = P == 1; writer.lead = lead; writer.off = off;
     writer.start();
-    bool copies_pending = false;
+    int last_set = -1;                                                                 // the set the previous record's D2H copies went into
     std::vector<float> zeros(floats, 0.0f);                                            // vort_src before the first input (main.cpp:110 leaves it uninitialised)
     char filename[1024];
 
     snprintf(filename, sizeof filename, "%s/%s", cfg.input.c_str(), cfg.init_file.c_str());
     {   // readField (main.cpp:143-144) into a pinned buffer; a rank reads its rows of the file (fieldio.cpp:21-33 reads all of it)
-        float *h0 = writer.h[0];
+        float *h0 = writer.h[0][0];
         if (P == 1) must(fb_read_field(filename, h0, floats), "readField");
         else {
             const int fd = open(filename, O_RDONLY);
@@ -409,12 +434,11 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
             stamp(t_end);
             ++n_records;
             auto h0 = std::chrono::steady_clock::now();
-            writer.wait_idle();                                                        // pinned buffers are free again
+            const int set = writer.acquire();                                          // a set of pinned buffers the writer is done with
             host_wait_s += since(h0);
-            if (copies_pending) eng->wait(e_copy);                                     // device record buffers are free again
+            if (last_set >= 0) eng->wait(writer.e_copy[last_set]);                     // device record buffers are free again: the previous record's copies have left them
             feed.hold(feed.cur);                                                       // vort_src as of this step (dumped BEFORE this step's read)
-            writer.src = feed.cur >= 0 ? feed.pin[feed.cur] : zeros.data();
-            writer.src_buf = feed.cur;
+            RecordWriter::Job job{step, set, feed.cur >= 0 ? feed.pin[feed.cur] : zeros.data(), feed.cur};
             h0 = std::chrono::steady_clock::now();
             eng->get(d_out[0], d_out[1], d_out[2], d_out[3]);
             host_get_s += since(h0);
@@ -426,11 +450,11 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
             eng->record(e_rec);
             must(fb_stream_wait_event(copy, e_rec), "wait");
             h0 = std::chrono::steady_clock::now();
-            for (int i = 0; i < 7; ++i) if (use[i]) must(fb_memcpy_d2h_async(copy, writer.h[i], d_out[i], floats * sizeof(float)), "d2h");
+            for (int i = 0; i < 7; ++i) if (use[i]) must(fb_memcpy_d2h_async(copy, writer.h[set][i], d_out[i], floats * sizeof(float)), "d2h");
             host_copy_s += since(h0);
-            must(fb_event_record(e_copy, copy), "record");
-            copies_pending = true;
-            writer.submit(step);
+            must(fb_event_record(writer.e_copy[set], copy), "record");
+            last_set = set;
+            writer.submit(job);
             stamp(t_beg);
         }
         if (cfg.recipe_type != EMPTY) {                                                // main-shallow-water.cpp:304
@@ -479,17 +503,17 @@ static void run_rank(const Config &cfg, int rank, void *hub, FILE *log_fd, bool 
                     wall_s, gpu_ms * 1e-3, rec_ms * 1e-3, tail_s, wall_s - gpu_ms * 1e-3 - rec_ms * 1e-3 - tail_s);
             // The host runs a stretch ahead of the GPU and then waits here for the previous record's files; the compute stream only runs dry
             // when ONE record's files take longer than the stretch between two records minus its D2H copies (the slowest record tells).
-            fprintf(stderr, "[timing] host time inside the %d record branches: %.3f s waiting for the writer thread, %.3f s enqueueing the record kernels, %.3f s in the D2H copy calls; "
+            fprintf(stderr, "[timing] host time inside the %d record branches: %.3f s waiting for a free set of record buffers (%d set%s), %.3f s enqueueing the record kernels, %.3f s in the D2H copy calls; "
                             "slowest record %.3f s to write, a stretch between records is %.3f s of stepping\n",
-                    n_records, host_wait_s, host_get_s, host_copy_s, writer.slowest_s, n_records > 0 ? gpu_ms * 1e-3 * cfg.record_step / steps : 0.0);
+                    n_records, host_wait_s, writer.nsets, writer.nsets > 1 ? "s" : "", host_get_s, host_copy_s, writer.slowest_s, n_records > 0 ? gpu_ms * 1e-3 * cfg.record_step / steps : 0.0);
             fflush(stderr);
         }
     }
     if (feed_done) delete feedp;
     fb_free(d_in); for (auto p : d_out) if (p) fb_free(p);
-    for (int i = 0; i < 7; ++i) if (writer.h[i]) fb_free_host(writer.h[i]);
+    for (int b = 0; b < 2; ++b) { for (int i = 0; i < 7; ++i) if (writer.h[b][i]) fb_free_host(writer.h[b][i]); if (writer.e_copy[b]) fb_event_destroy(writer.e_copy[b]); }
     delete eng;
-    for (void *e : {e_rec, e_copy, e_h2d, e_src}) fb_event_destroy(e);
+    for (void *e : {e_rec, e_h2d, e_src}) fb_event_destroy(e);
     fb_stream_destroy(copy);
 }
 
@@ -501,7 +525,7 @@ int main(int argc, char *args[])
                                     {"steps", 1, 0, 6}, {"record-step", 1, 0, 7}, {"start-step", 1, 0, 8},
                                     {"world", 1, 0, 9}, {"rank", 1, 0, 10}, {"comm-file", 1, 0, 11}, {"ranks-as-threads", 0, 0, 12},
                                     {"launch-token", 1, 0, 13}, {"comm-max-age", 1, 0, 14}, {"comm-timeout", 1, 0, 15}, {"fifo-fanout", 0, 0, 16},
-                                    {"no-timing", 0, 0, 17}, {"dump-grad-vort", 0, 0, 18}, {"dump-dvortdt", 0, 0, 19},
+                                    {"no-timing", 0, 0, 17}, {"dump-grad-vort", 0, 0, 18}, {"dump-dvortdt", 0, 0, 19}, {"record-buffers", 1, 0, 20},
                                     {0, 0, 0, 0}};
     int opt;
     while ((opt = getopt_long(argc, args, "I:O:i:s:f:", lopts, NULL)) != EOF) {      // main.cpp:68-80, main-shallow-water.cpp:75-95
@@ -529,7 +553,8 @@ int main(int argc, char *args[])
         case 16: cfg.fanout = true; break;
         case 17: cfg.timing = false; break;
         case 18: cfg.dump_grad = true; break;            // main.cpp:156-162,170-176 (#ifdef OUTPUT_GRAD_VORT; configuration.hpp:4-5 defines only OUTPUT_PSI and OUTPUT_WIND)
-        case 19: cfg.dump_dvortdt = true; break;         // main.cpp:229-235 (#ifdef OUTPUT_DVORTDT)
+        case 19: cfg.dump_dvortdt = true; break;
+        case 20: cfg.record_buffers = atoi(optarg); break;         // main.cpp:229-235 (#ifdef OUTPUT_DVORTDT)
         }
     }
     if (cfg.world < 1 || cfg.rank < 0 || cfg.rank >= cfg.world || (cfg.world > 1 && !cfg.threads && cfg.comm_file.empty()) ||
