@@ -19,8 +19,11 @@ w = re.search(r"\): ([0-9.]+) steps/s over", t).group(1)
 r = re.search(r"([0-9.]+) s with a record step holding", t).group(1)
 g = re.search(r"= ([0-9.]+) GB/s to", t).group(1)
 s = re.search(r"slowest record ([0-9.]+) s to write, a stretch between records is ([0-9.]+) s", t).groups()
-print("record-buffers %s: compute-only %s steps/s, with records %s steps/s (%.1f %% less); record steps held the compute stream %s s; writer %s GB/s, slowest record %s s (stretch %s s)"
-      % (sys.argv[1], c, w, 100 * (1 - float(w) / float(c)), r, g, s[0], s[1]))
+tail, un = re.search(r"([0-9.]+) s between the last step's end and the last file \(writer tail\), (-?[0-9.]+) s unaccounted", t).groups()
+hw = re.search(r"branches: ([0-9.]+) s waiting for a free set", t).group(1)
+print("record-buffers %s: compute-only %s steps/s, with records %s steps/s (%.1f %% less); record steps held the compute stream %s s, writer tail %s s, unaccounted %s s; "
+      "writer %s GB/s, slowest record %s s (stretch %s s); host waited %s s for a buffer set"
+      % (sys.argv[1], c, w, 100 * (1 - float(w) / float(c)), r, tail, un, g, s[0], s[1], hw))
 PY
   done
 done
