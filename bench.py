@@ -162,7 +162,9 @@ def parse_args(argv=None):
     ap.add_argument("--driver-steps", type=int, default=None,
                     help="N=1: the `driver` leg -- the C++ drop-in driver (host/barotropic_main.out) on the same workload for this many steps with "
                          "record_step 100 (configuration.hpp:34-36), records into a temporary directory (default: 1000 at the default grid, else 0 = off)")
-    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N>1 started from a plain shell: seconds before the child job is ended")
+    ap.add_argument("--launch-timeout", type=float, default=540.0,
+                    help="N>1 started from a plain shell: seconds before the child job (its whole process group) is ended; the headline line rank 0 has "
+                         "left by then is still printed, marked incomplete (an 8-rank job with its two configs takes about 1.5 minutes)")
     return ap.parse_args(argv)
 
 
@@ -186,38 +188,63 @@ def self_launch(args):
     env["FB_BENCH_LINE_FILE"] = line_file                      # rank 0 leaves the line here as soon as the headline run is done
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
-    timed_out = []
+    # The ranks live in a session of their own so that exactly THEIR process group can be ended -- which also means nobody else ends them:
+    # if this parent is told to stop (a harness time limit, Ctrl-C) it must take them along, or they stay on the node's GPUs.
+    def die_with_parent():                                      # in the launcher, between fork and exec: PR_SET_PDEATHSIG = 1
+        import ctypes
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGTERM))
+    # (a SIGKILL to this parent cannot be caught here; the kernel then tells the launcher, which shuts its workers down)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True, preexec_fn=die_with_parent)
+    state = {"why": None}
 
-    def end_child():
-        timed_out.append(True)
-        try:
-            os.killpg(child.pid, signal.SIGTERM)                # the exact process group started above
-            time.sleep(10)
-            os.killpg(child.pid, signal.SIGKILL)
-        except (ProcessLookupError, PermissionError):
-            pass
-    timer = threading.Timer(args.launch_timeout, end_child)
+    def end_child(why):
+        if state["why"] is None:
+            state["why"] = why
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 0.0)):
+            try:
+                os.killpg(child.pid, sig)                       # the exact process group started above
+            except (ProcessLookupError, PermissionError):
+                return
+            t_end = time.time() + grace
+            while time.time() < t_end:
+                if child.poll() is not None:
+                    break
+                time.sleep(0.2)
+
+    def on_signal(signum, frame):
+        raise KeyboardInterrupt("signal %d" % signum)
+    old_handlers = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    timer = threading.Timer(args.launch_timeout, end_child, args=("launch timeout of %g s" % args.launch_timeout,))
     timer.daemon = True
     timer.start()
-    line = None
-    for ln in child.stdout:
-        t = ln.strip()
-        if t.startswith("{") and t.endswith("}"):
-            try:
-                json.loads(t)
-                line = t
-                continue
-            except ValueError:
-                pass
-        sys.stderr.write(ln)
-    rc = child.wait()
-    timer.cancel()
+    line, rc = None, None
+    try:
+        for ln in child.stdout:
+            t = ln.strip()
+            if t.startswith("{") and t.endswith("}"):
+                try:
+                    json.loads(t)
+                    line = t
+                    continue
+                except ValueError:
+                    pass
+            sys.stderr.write(ln)
+        rc = child.wait()
+    except KeyboardInterrupt as e:                              # this parent was told to stop: the ranks go first
+        end_child("the parent was stopped (%s)" % e)
+        rc = child.wait()
+    finally:
+        timer.cancel()
+        if child.poll() is None:                                # whatever brought us here, no rank outlives the parent
+            end_child("parent leaving")
+            child.wait()
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     if line is None:                                            # the job ended after the headline run but before its last line
         try:
             d = json.load(open(line_file))
-            d["incomplete"] = "the ranks ended (rc %d%s) after the headline run and before the final line; this is the line as of the headline run" % (
-                rc, ", launch timeout" if timed_out else "")
+            d["incomplete"] = "the ranks ended (rc %s%s) after the headline run and before the final line; this is the line as of the headline run" % (
+                rc, ", " + state["why"] if state["why"] else "")
             line = json.dumps(d)
         except (OSError, ValueError):
             pass
@@ -226,9 +253,11 @@ def self_launch(args):
     except OSError:
         pass
     if line is not None:
-        print(line)
+        print(line, flush=True)
     else:
-        sys.stderr.write("bench.py: the %d-rank job printed no line (rc %d)\n" % (args.gpus, rc))
+        sys.stderr.write("bench.py: the %d-rank job printed no line (rc %s%s)\n" % (args.gpus, rc, ", " + state["why"] if state["why"] else ""))
+    if state["why"] and state["why"].startswith("the parent was stopped"):
+        return 130
     return rc if rc else (0 if line is not None else 1)
 
 

@@ -240,3 +240,106 @@ def test_bench_parent_reports_a_failed_child_job(tmp_path):
     assert "printed no line" in res.stderr
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "os.exec" not in src and "execv" not in src
+
+
+_FAKE_RANK = r'''
+import json, os, sys, time
+open(os.path.join(%(dir)r, "pid.%%s" %% os.environ["RANK"]), "w").write(str(os.getpid()))
+if os.environ["RANK"] == "0":
+    with open(os.environ["FB_BENCH_LINE_FILE"], "w") as f:
+        json.dump({"metric": "stand-in", "value": 1.0, "n_gpus": int(os.environ["WORLD_SIZE"])}, f)
+time.sleep(600)                      # a job that hangs after its headline run
+'''
+_PARENT = r'''
+import sys
+sys.path.insert(0, %(root)r)
+import bench
+bench.__file__ = %(rank)r            # self_launch starts `torch.distributed.run <this file> <args>`
+sys.argv = ["bench.py", "--gpus", "2", "--launch-timeout", %(timeout)r]
+raise SystemExit(bench.self_launch(bench.parse_args(sys.argv[1:])))
+'''
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+    try:                                                     # a zombie waiting to be reaped does not count as running
+        return open("/proc/%d/stat" % pid).read().split(")")[-1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def _wait_for_pids(tmp_path, n, timeout=120):
+    import time
+    t_end = time.time() + timeout
+    while time.time() < t_end:
+        got = [p for p in (tmp_path / ("pid.%d" % r) for r in range(n)) if p.exists() and p.read_text().strip()]
+        if len(got) == n:
+            return [int(p.read_text()) for p in got]
+        time.sleep(0.5)
+    raise AssertionError("the stand-in ranks did not start")
+
+
+def _launch_parent(tmp_path, timeout_s):
+    import subprocess
+    rank = tmp_path / "fake_rank.py"
+    rank.write_text(_FAKE_RANK % {"dir": str(tmp_path)})
+    parent = tmp_path / "parent.py"
+    parent.write_text(_PARENT % {"root": ROOT, "rank": str(rank), "timeout": str(timeout_s)})
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.Popen([sys.executable, str(parent)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=str(tmp_path))
+
+
+def test_bench_parent_ends_a_hung_job_and_still_prints_the_headline_line(tmp_path):
+    """bench.self_launch with ranks that hang after their headline run (a stand-in rank script: no GPU needed): when --launch-timeout
+    expires the parent ends the ranks' whole process group, prints the line rank 0 had left, marked `incomplete`, and returns non-zero;
+    no rank is left behind."""
+    import json
+    import time
+    p = _launch_parent(tmp_path, 20)
+    pids = _wait_for_pids(tmp_path, 2)
+    out, err = p.communicate(timeout=180)
+    assert p.returncode != 0
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, (out, err[-1500:])
+    d = json.loads(lines[0])
+    assert d["metric"] == "stand-in" and d["n_gpus"] == 2 and "launch timeout" in d["incomplete"]
+    time.sleep(1.0)
+    assert not any(_alive(pid) for pid in pids), pids
+
+
+def test_bench_parent_takes_its_ranks_along_when_it_is_stopped(tmp_path):
+    """The ranks run in a session of their own (so that exactly their process group can be ended), hence nobody but the parent ends them:
+    a SIGTERM to the parent -- a harness time limit -- must not leave them on the node's GPUs.  Stand-in ranks, no GPU needed."""
+    import json
+    import signal
+    import time
+    p = _launch_parent(tmp_path, 500)
+    pids = _wait_for_pids(tmp_path, 2)
+    assert all(_alive(pid) for pid in pids)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=120)
+    assert p.returncode == 130, (p.returncode, err[-1500:])
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and "the parent was stopped" in json.loads(lines[0])["incomplete"]      # even then: the headline line
+    time.sleep(1.0)
+    assert not any(_alive(pid) for pid in pids), pids
+
+
+def test_bench_ranks_do_not_outlive_a_killed_parent(tmp_path):
+    """SIGKILL cannot be handled: the launcher is started with PR_SET_PDEATHSIG, so the kernel sends it SIGTERM when the parent dies and
+    torch.distributed.run shuts its workers down.  Stand-in ranks, no GPU needed."""
+    import signal
+    import time
+    p = _launch_parent(tmp_path, 500)
+    pids = _wait_for_pids(tmp_path, 2)
+    p.send_signal(signal.SIGKILL)
+    p.communicate(timeout=60)
+    t_end = time.time() + 90                                  # the elastic agent gives its workers a grace period
+    while time.time() < t_end and any(_alive(pid) for pid in pids):
+        time.sleep(1.0)
+    assert not any(_alive(pid) for pid in pids), pids
