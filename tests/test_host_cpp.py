@@ -139,6 +139,47 @@ def test_driver_optional_debug_dumps(tmp_path):
 
 
 @pytest.mark.gpu
+def test_driver_record_path_under_pressure_one_and_two_buffer_sets(tmp_path):
+    """The record path with the writer thread permanently behind: 256^2 (a step takes ~0.1 ms), a record every 3 steps, 61 steps = 21
+    records of five files -- every set of pinned record buffers is always queued or being written, so the step loop sits in
+    RecordWriter::acquire() and the job queue is never empty.  --record-buffers 1 (round 3's behaviour: wait for the previous record's files)
+    and 2 (round 4) must give the same ./log, in main.cpp:266-282's order, and the same bytes in every file; the last record checked
+    against the Python binding on the same library bit for bit (a record mixed up with a later step's copies would differ)."""
+    import xlab_fftbarotropic_amd as X
+    _build()
+    n, steps, every = 256, 61, 3
+    v0 = X.make_field("elliptic", n)
+    runs = {}
+    for sets in ("1", "2"):
+        d = tmp_path / ("sets" + sets)
+        (d / "input").mkdir(parents=True)
+        (d / "output").mkdir()
+        v0.tofile(str(d / "input" / "initial_vorticity.bin"))
+        res = subprocess.run([os.path.join(HOST, "barotropic_main.out"), "--npts", str(n), "--steps", str(steps), "--record-step", str(every),
+                              "--record-buffers", sets], cwd=str(d), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-1500:]
+        assert ("(%s set%s)" % (sets, "" if sets == "1" else "s")) in res.stderr
+        log = (d / "log").read_text().split()
+        runs[sets] = (log, {f: (d / f).read_bytes() for f in log})
+    want_log = ["output/%s_step_%d.bin" % (name, s) for s in range(0, steps, every) for name in ("vort_src_input", "vort", "psi", "u", "v")]
+    assert runs["1"][0] == want_log and runs["2"][0] == want_log
+    for f in want_log:
+        assert runs["1"][1][f] == runs["2"][1][f], f
+        assert len(runs["2"][1][f]) == n * n * 4
+    m = X.Model(n, n)
+    m.set_vort(v0)
+    m.step(60)
+    psi, u, v = m.diag()
+    last = lambda name: np.frombuffer(runs["2"][1]["output/%s_step_60.bin" % name], dtype="<f4").reshape(n, n)
+    assert np.array_equal(last("vort"), m.vort().cpu().numpy()) and np.array_equal(last("psi"), psi.cpu().numpy())
+    assert np.array_equal(last("u"), u.cpu().numpy()) and np.array_equal(last("v"), v.cpu().numpy())
+    mid = X.Model(n, n)                                      # ... and one from the middle of the queue
+    mid.set_vort(v0)
+    mid.step(30)
+    assert np.array_equal(np.frombuffer(runs["2"][1]["output/vort_step_30.bin"], dtype="<f4").reshape(n, n), mid.vort().cpu().numpy())
+
+
+@pytest.mark.gpu
 def test_driver_4096_default_path(tmp_path):
     """The drop-in driver on the benchmark grid (4096^2 Kuo2004, dt = 0.75 s): there the engine takes its
     single-pass x transform and the digit-permutation row kernel, and the record path (get_vort / get_diag)
