@@ -139,6 +139,54 @@ def test_driver_optional_debug_dumps(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sets", ["1", "2"])
+def test_driver_fifo_source_every_step_with_records_in_flight(tmp_path, sets):
+    """The FIFO source's three pinned buffers (SourceFeed) against a writer that holds sources for the records it has queued: a NEW source
+    with every step (flag 1 + GRIDS float32 per step, vorticity_source.cpp:112-133), a record every 2 steps, 128^2 so that the writer is
+    always behind -- with two buffer sets two queued records can hold two different old sources while a third is current and the reader
+    thread wants a fourth.  The run must finish (no thread waits on another in a cycle: the writer never waits for the step loop or the
+    reader), every vort_src_input_step_k.bin must be the source in force BEFORE step k's read (main-shallow-water.cpp:304 comes after the
+    dump), and the last vort record must equal the Python binding fed the same sources step by step, bit for bit."""
+    import threading
+    import xlab_fftbarotropic_amd as X
+    _build()
+    n, steps, every = 128, 41, 2
+    (tmp_path / "input").mkdir()
+    (tmp_path / "output").mkdir()
+    v0 = X.make_field("kuo2004", n)
+    v0.tofile(str(tmp_path / "input" / "initial_vorticity.bin"))
+    rng = np.random.default_rng(77)
+    srcs = [(rng.standard_normal((n, n)) * 1e-9).astype(np.float32) for _ in range(steps)]        # srcs[k] arrives with step k's read
+    fifo = str(tmp_path / "vort_src_fifo")
+    os.mkfifo(fifo)
+    p = subprocess.Popen([os.path.join(HOST, "barotropic_main.out"), "-f", fifo, "--npts", str(n), "--steps", str(steps), "--record-step", str(every),
+                          "--record-buffers", sets], cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+    def produce():
+        with open(fifo, "wb") as f:
+            for k in range(steps):
+                f.write(b"\x01" + srcs[k].tobytes())
+    t = threading.Thread(target=produce, daemon=True)
+    t.start()
+    try:
+        assert p.wait(timeout=180) == 0                      # a deadlock between reader, step loop and writer would end here
+    finally:
+        if p.poll() is None:
+            p.kill()
+    t.join(timeout=30)
+    rd = lambda name: np.fromfile(str(tmp_path / "output" / name), dtype="<f4").reshape(n, n)
+    for k in range(0, steps, every):
+        want = np.zeros((n, n), dtype=np.float32) if k == 0 else srcs[k - 1]                      # dumped before step k's own read
+        assert np.array_equal(rd("vort_src_input_step_%d.bin" % k), want), k
+    m = X.Model(n, n)
+    m.set_vort(v0)
+    for k in range(steps - 1):                               # the last record is taken at step 40, before that step is computed
+        m.set_source(srcs[k])
+        m.step(1)
+    assert np.array_equal(rd("vort_step_%d.bin" % (steps - 1)), m.vort().cpu().numpy())
+
+
+@pytest.mark.gpu
 def test_driver_record_path_under_pressure_one_and_two_buffer_sets(tmp_path):
     """The record path with the writer thread permanently behind: 256^2 (a step takes ~0.1 ms), a record every 3 steps, 61 steps = 21
     records of five files -- every set of pinned record buffers is always queued or being written, so the step loop sits in
