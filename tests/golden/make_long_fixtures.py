@@ -12,7 +12,8 @@ Run in the build container only (the GPU box never regenerates them):
       configs[1] -- 1024^2 elliptic vortex, dt = 3 s -- sub-sampled (every 4th point) after 1000 steps: the
       oracle's own 1000-step cross-check.
 
-  oracle_8192_step300.npz   : the oracle on BASELINE configs[3] -- 8192^2 gaussian vortex (makefield-gaussian.cpp:14-31),
+  oracle_8192_step300.npz   : (round 3; retired in round 4: oracle_8192_step1000.npz from `oracle8192_1000` reproduces it bit for bit at steps 10 / 100 / 300
+      and goes on to 600 and 1000)  the oracle on BASELINE configs[3] -- 8192^2 gaussian vortex (makefield-gaussian.cpp:14-31),
       dt = 0.375 s -- vort[::32, ::32] after 10, 100 and 300 steps, full-field L2 norms and sums (~1 h on 5 cores, 5 GiB).
   oracle_16384_src_step12.npz : the oracle on BASELINE configs[4] -- 16384^2 Kuo2004 initial field, the source-forced loop
       of main-shallow-water.cpp:277-338 with the FIFO producer's schedule (vort_src_input.cpp:35-61) shifted so that it is
